@@ -1,0 +1,83 @@
+// Shared host/device helpers for liborn.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/orn.h"
+
+#define ORN_WAVE 64
+
+// ---- error plumbing --------------------------------------------------------------------------
+void orn_set_error(const char *fmt, ...);
+
+#define ORN_REQUIRE(cond, ...)                         \
+    do {                                               \
+        if (!(cond)) {                                 \
+            orn_set_error(__VA_ARGS__);                \
+            return ORN_E_ARG;                          \
+        }                                              \
+    } while (0)
+
+#define ORN_LAUNCH_CHECK(name)                                              \
+    do {                                                                    \
+        hipError_t e__ = hipGetLastError();                                 \
+        if (e__ != hipSuccess) {                                            \
+            orn_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return (int)e__;                                                \
+        }                                                                   \
+    } while (0)
+
+#define ORN_TRY(expr)                 \
+    do {                              \
+        int rc__ = (expr);            \
+        if (rc__ != 0) return rc__;   \
+    } while (0)
+
+static inline int orn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline size_t orn_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// ---- device helpers --------------------------------------------------------------------------
+__device__ __forceinline__ float orn_sigmoid(float z) { return 1.0f / (1.0f + __expf(-z)); }
+__device__ __forceinline__ float orn_silu(float z) { return z / (1.0f + __expf(-z)); }
+// d/dz [z*sigmoid(z)] = s*(1 + z*(1-s))
+__device__ __forceinline__ float orn_silu_grad(float z)
+{
+    const float s = 1.0f / (1.0f + __expf(-z));
+    return s * (1.0f + z * (1.0f - s));
+}
+
+// exact-mode variants (accurate expf): used by the fp32 path
+__device__ __forceinline__ float orn_silu_exact(float z) { return z / (1.0f + expf(-z)); }
+__device__ __forceinline__ float orn_silu_grad_exact(float z)
+{
+    const float s = 1.0f / (1.0f + expf(-z));
+    return s * (1.0f + z * (1.0f - s));
+}
+
+__device__ __forceinline__ float orn_wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (multiple of 64); result valid in thread 0. Deterministic.
+__device__ __forceinline__ float orn_block_sum(float v, float *smem /* >= 16 floats */)
+{
+    v = orn_wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) smem[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 0; i < nw; ++i) r += smem[i];
+    }
+    return r;
+}
+
+// ---- internal cross-file entry points (not exported) -----------------------------------------
+// Generic deterministic column reduce: out[j] = sum_{i<rows} in[i*ld + j], fixed order.
+int orn_launch_reduce_rows(const float *in, int rows, size_t ld, size_t n, float *out, hipStream_t st);

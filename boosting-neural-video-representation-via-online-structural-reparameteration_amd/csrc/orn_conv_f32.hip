@@ -1,0 +1,383 @@
+// A4  NeRVBlock conv path in exact fp32 (model.py:539,567 and its autograd backward):
+//   fwd   : y = conv3x3(x, Wf, bf, pad 1)  ->  z = PixelShuffle_s(y)  ->  a = SiLU(z)
+//   bwd   : dy = unshuffle(da * SiLU'(z));  dbf = sum_hw dy;  dWf = wgrad(x, dy);  dx = dgrad(dy, Wf)
+//
+// All three contractions are implicit GEMMs on v_mfma_f32_32x32x2_f32 (exact fp32, one rounding per
+// product, fp32 accumulate), operands staged through LDS, tensors NCHW fp32 exactly as PyTorch holds
+// them.  MFMA bound: roofline = 157.3 TFLOP/s (fp32 matrix).
+//
+// Lane maps (MI355X guide): A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D col = l&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+#include "orn_common.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// ================================================================================================
+// Implicit-GEMM 3x3 conv (pad 1, stride 1).  D rows = output channel, D cols = 32 pixels of a row.
+// Work-group tile: 64 output channels x (8 rows x 32 cols); 4 waves, wave w owns rows 2w, 2w+1.
+// K loop: chunks of 8 input channels; MFMA step t=(cp,ij) contracts channels {cp, cp+4} (lane half
+// picks one) at tap ij -- any K permutation is a legal fp32 summation order for the conv.
+// ================================================================================================
+#define CV_BO 64
+#define CV_TH 8
+#define CV_TW 32
+#define CV_CC 8
+#define CV_XW (CV_TW + 2)
+#define CV_XH (CV_TH + 2)
+#define CV_WLD (CV_CC * 9 + 1)
+
+enum { EPI_PLAIN = 0, EPI_PS_SILU = 1 };
+
+struct ConvP {
+    const float *x;     // [B, C, H, W]
+    const float *w;     // [O, C, 3, 3]
+    const float *bias;  // [O] or null
+    float *out;         // EPI_PLAIN: [B,O,H,W];  EPI_PS_SILU: a [B,Cn,H*s,W*s]
+    float *z;           // EPI_PS_SILU: pre-activation (may be null)
+    int B, C, O, H, W, s;
+    int tiles_w, tiles_h;
+};
+
+template <int EPI>
+__global__ void __launch_bounds__(256) k_conv3x3_f32(ConvP p)
+{
+    __shared__ float Xs[CV_CC][CV_XH][CV_XW];
+    __shared__ float Ws[CV_BO][CV_WLD];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int tile = blockIdx.x;
+    const int tw = tile % p.tiles_w, th = tile / p.tiles_w;
+    const int h0 = th * CV_TH, w0 = tw * CV_TW;
+    const int o0 = blockIdx.y * CV_BO;
+    const int b = blockIdx.z;
+    const int C = p.C, H = p.H, W = p.W;
+    const float *xb = p.x + (size_t)b * C * H * W;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int r0 = wave * 2;                   // first of the wave's two output rows (tile-local)
+    for (int c0 = 0; c0 < C; c0 += CV_CC) {
+        // ---- stage the input patch (zero padded) and the weight tile --------------------------
+        for (int idx = t; idx < CV_CC * CV_XH * CV_XW; idx += 256) {
+            const int c = idx / (CV_XH * CV_XW);
+            const int rem = idx - c * (CV_XH * CV_XW);
+            const int r = rem / CV_XW, xx = rem - r * CV_XW;
+            const int gh = h0 + r - 1, gw = w0 + xx - 1, gc = c0 + c;
+            float v = 0.f;
+            if (gc < C && gh >= 0 && gh < H && gw >= 0 && gw < W) v = xb[((size_t)gc * H + gh) * W + gw];
+            (&Xs[0][0][0])[idx] = v;
+        }
+        for (int idx = t; idx < CV_BO * CV_CC * 9; idx += 256) {
+            const int o = idx / (CV_CC * 9), kk = idx - o * (CV_CC * 9);
+            float v = 0.f;
+            if (o0 + o < p.O && c0 * 9 + kk < C * 9) v = p.w[(size_t)(o0 + o) * C * 9 + (size_t)c0 * 9 + kk];
+            Ws[o][kk] = v;
+        }
+        __syncthreads();
+        // ---- 36 MFMA k-steps ---------------------------------------------------------------------
+#pragma unroll
+        for (int cp = 0; cp < CV_CC / 2; ++cp) {
+            const int ch = cp + (CV_CC / 2) * hh;
+            float xv[4][3];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) xv[r][j] = Xs[ch][r0 + r][l31 + j];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float a0 = Ws[l31][ch * 9 + i * 3 + j];
+                    const float a1 = Ws[32 + l31][ch * 9 + i * 3 + j];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, xv[i][j], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, xv[i + 1][j], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, xv[i][j], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, xv[i + 1][j], acc[1][1], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------------
+    const int gw = w0 + l31;
+    if (gw >= W) return;
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int gh = h0 + r0 + rr;
+            if (gh >= H) continue;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int o = o0 + ob * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                if (o >= p.O) continue;
+                float v = acc[ob][rr][reg];
+                if (p.bias) v += p.bias[o];
+                if (EPI == EPI_PLAIN) {
+                    p.out[(((size_t)b * p.O + o) * H + gh) * W + gw] = v;
+                } else {
+                    const int s = p.s, ss = s * s;
+                    const int n = o / ss, rem = o - n * ss, si = rem / s, sj = rem - si * s;
+                    const int Cn = p.O / ss;
+                    const size_t idx = (((size_t)b * Cn + n) * (H * s) + (gh * s + si)) * (size_t)(W * s) + (gw * s + sj);
+                    if (p.z) p.z[idx] = v;
+                    p.out[idx] = orn_silu_exact(v);
+                }
+            }
+        }
+}
+
+int orn_launch_conv3x3_f32(const float *x, const float *w, const float *bias, int B, int C, int O, int H, int W,
+                           int s, int epi, float *z, float *out, hipStream_t st)
+{
+    ConvP p;
+    p.x = x; p.w = w; p.bias = bias; p.out = out; p.z = z;
+    p.B = B; p.C = C; p.O = O; p.H = H; p.W = W; p.s = s;
+    p.tiles_w = orn_cdiv(W, CV_TW);
+    p.tiles_h = orn_cdiv(H, CV_TH);
+    dim3 grid(p.tiles_w * p.tiles_h, orn_cdiv(O, CV_BO), B);
+    if (epi == EPI_PS_SILU) hipLaunchKernelGGL(k_conv3x3_f32<EPI_PS_SILU>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(k_conv3x3_f32<EPI_PLAIN>, grid, dim3(256), 0, st, p);
+    ORN_LAUNCH_CHECK("conv3x3_f32");
+    return 0;
+}
+
+extern "C" int orn_conv3x3_ps_silu_fwd(const float *x, const float *wf, const float *bf, int B, int C, int O, int H,
+                                       int W, int s, float *z, float *a, void *stream)
+{
+    ORN_REQUIRE(x && wf && a, "conv3x3_ps_silu_fwd: null pointer");
+    ORN_REQUIRE(B > 0 && C > 0 && O > 0 && H > 0 && W > 0 && s > 0, "conv3x3_ps_silu_fwd: bad sizes");
+    ORN_REQUIRE(O % (s * s) == 0, "conv3x3_ps_silu_fwd: O=%d not divisible by s*s=%d", O, s * s);
+    return orn_launch_conv3x3_f32(x, wf, bf, B, C, O, H, W, s, EPI_PS_SILU, z, a, (hipStream_t)stream);
+}
+
+// ================================================================================================
+// dy[b,o,h,w] = da[b,n,hs+i,ws+j] * SiLU'(z[b,n,hs+i,ws+j]),  o = n*s*s + i*s + j      (+ dbias partials)
+// grid: (chunks, O, B); each block sums its chunk -> partial[(b*chunks + chunk)*O + o]
+// ================================================================================================
+#define DY_PPB 2048
+__global__ void __launch_bounds__(256)
+k_silu_bwd_unshuffle(const float *__restrict__ da, const float *__restrict__ z, int O, int H, int W, int s,
+                     float *__restrict__ dy, float *__restrict__ partial)
+{
+    __shared__ float sred[16];
+    const int o = blockIdx.y, b = blockIdx.z, chunk = blockIdx.x;
+    const int ss = s * s, n = o / ss, rem = o - n * ss, si = rem / s, sj = rem - si * s;
+    const int Cn = O / ss;
+    const size_t HW = (size_t)H * W;
+    const size_t Ws = (size_t)W * s;
+    const float *dab = da + ((size_t)b * Cn + n) * HW * ss;
+    const float *zb = z + ((size_t)b * Cn + n) * HW * ss;
+    float *dyb = dy + ((size_t)b * O + o) * HW;
+    float sum = 0.f;
+    const size_t p0 = (size_t)chunk * DY_PPB;
+    for (int i = threadIdx.x; i < DY_PPB; i += 256) {
+        const size_t pix = p0 + i;
+        if (pix < HW) {
+            const int h = (int)(pix / W), w = (int)(pix - (size_t)h * W);
+            const size_t src = (size_t)(h * s + si) * Ws + (size_t)(w * s + sj);
+            const float v = dab[src] * orn_silu_grad_exact(zb[src]);
+            dyb[pix] = v;
+            sum += v;
+        }
+    }
+    const float tot = orn_block_sum(sum, sred);
+    if (threadIdx.x == 0) partial[((size_t)b * gridDim.x + chunk) * O + o] = tot;
+}
+
+// ================================================================================================
+// Weight transform for dgrad: Wd[c][o][i][j] = Wf[o][c][2-i][2-j]  (dx = conv3x3(dy, Wd, pad 1))
+// ================================================================================================
+__global__ void k_flip_transpose_w(const float *__restrict__ wf, int O, int C, float *__restrict__ wd)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)O * C * 9) return;
+    const int ij = (int)(idx % 9);
+    const long oc = idx / 9;
+    const int c = (int)(oc % C), o = (int)(oc / C);
+    wd[((long)c * O + o) * 9 + (8 - ij)] = wf[idx];
+}
+
+// ================================================================================================
+// wgrad: dW[o, n=(c,ij)] = sum_{b,h,w} dy[b,o,h,w] * x[b,c,h+i-1,w+j-1]
+// D rows = o (A operand = dy), D cols = n (B operand = shifted x), K = pixels.
+// Work-group tile 64 o x 128 n; K tile = 4 rows x 32 cols of pixels; split-K over pixel tiles with
+// per-split partial slabs reduced afterwards in fixed order (deterministic, no atomics).
+// ================================================================================================
+#define WG_BO 64
+#define WG_BN 128
+#define WG_TH 4
+#define WG_TW 32
+#define WG_NPX (WG_TH * WG_TW)
+#define WG_MAXC 16
+#define WG_XH (WG_TH + 2)
+#define WG_XW (WG_TW + 2)
+
+struct WgradP {
+    const float *x;    // [B,C,H,W]
+    const float *dy;   // [B,O,H,W]
+    float *partial;    // [S][O][C*9]
+    int B, C, O, H, W;
+    int tiles_w, tiles_h, n_ktiles, S, n_ntiles;
+};
+
+__global__ void __launch_bounds__(256) k_wgrad_f32(WgradP p)
+{
+    __shared__ float Ds[WG_BO][WG_NPX + 1];
+    __shared__ float Xs[WG_MAXC][WG_XH][WG_XW];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int ot = blockIdx.x / p.n_ntiles, nt = blockIdx.x - ot * p.n_ntiles;
+    const int o0 = ot * WG_BO, n0 = nt * WG_BN;
+    const int C = p.C, H = p.H, W = p.W, N = C * 9;
+    const int c_lo = n0 / 9;
+    const int wo = wave >> 1, wn = wave & 1;
+
+    // this lane's two output columns (n-blocks 2*wn, 2*wn+1) -> per-lane LDS base offsets
+    int xoff[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        int n = n0 + (2 * wn + q) * 32 + l31;
+        if (n >= N) n = N - 1;                          // clamp (masked at the store)
+        const int c = n / 9, ij = n - c * 9, i = ij / 3, j = ij - i * 3;
+        xoff[q] = ((c - c_lo) * WG_XH + i) * WG_XW + j + hh;
+    }
+    const int doff = (wo * 32 + l31) * (WG_NPX + 1) + hh;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    const int tiles_per_img = p.tiles_w * p.tiles_h;
+    for (int kt = blockIdx.y; kt < p.n_ktiles; kt += p.S) {
+        const int b = kt / tiles_per_img;
+        const int rem = kt - b * tiles_per_img;
+        const int th = rem / p.tiles_w, tw = rem - th * p.tiles_w;
+        const int h0 = th * WG_TH, w0 = tw * WG_TW;
+        const float *xb = p.x + (size_t)b * C * H * W;
+        const float *dyb = p.dy + (size_t)b * p.O * H * W;
+        for (int idx = t; idx < WG_BO * WG_NPX; idx += 256) {
+            const int o = idx / WG_NPX, px = idx - o * WG_NPX;
+            const int r = px / WG_TW, xx = px - r * WG_TW;
+            const int gh = h0 + r, gw = w0 + xx;
+            float v = 0.f;
+            if (o0 + o < p.O && gh < H && gw < W) v = dyb[((size_t)(o0 + o) * H + gh) * W + gw];
+            Ds[o][px] = v;
+        }
+        for (int idx = t; idx < WG_MAXC * WG_XH * WG_XW; idx += 256) {
+            const int c = idx / (WG_XH * WG_XW);
+            const int rem2 = idx - c * (WG_XH * WG_XW);
+            const int r = rem2 / WG_XW, xx = rem2 - r * WG_XW;
+            const int gh = h0 + r - 1, gw = w0 + xx - 1, gc = c_lo + c;
+            float v = 0.f;
+            if (gc < C && gh >= 0 && gh < H && gw >= 0 && gw < W) v = xb[((size_t)gc * H + gh) * W + gw];
+            (&Xs[0][0][0])[idx] = v;
+        }
+        __syncthreads();
+        const float *dsp = &Ds[0][0] + doff;
+        const float *xs0 = &Xs[0][0][0] + xoff[0];
+        const float *xs1 = &Xs[0][0][0] + xoff[1];
+#pragma unroll
+        for (int r = 0; r < WG_TH; ++r)
+#pragma unroll
+            for (int x2 = 0; x2 < WG_TW; x2 += 2) {
+                const float a = dsp[r * WG_TW + x2];
+                const float b0 = xs0[r * WG_XW + x2];
+                const float b1 = xs1[r * WG_XW + x2];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+            }
+        __syncthreads();
+    }
+
+    float *out = p.partial + (size_t)blockIdx.y * p.O * N;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int n = n0 + (2 * wn + q) * 32 + l31;
+        if (n >= N) continue;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int o = o0 + wo * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+            if (o < p.O) out[(size_t)o * N + n] = acc[q][reg];
+        }
+    }
+}
+
+static int wgrad_split(int B, int C, int O, int H, int W)
+{
+    const int n_ktiles = B * orn_cdiv(H, WG_TH) * orn_cdiv(W, WG_TW);
+    const int tiles = orn_cdiv(O, WG_BO) * orn_cdiv(C * 9, WG_BN);
+    int S = orn_cdiv(1024, tiles);
+    if (S > n_ktiles) S = n_ktiles;
+    if (S < 1) S = 1;
+    return S;
+}
+
+extern "C" size_t orn_conv3x3_ps_silu_bwd_ws_bytes(int B, int C, int O, int H, int W)
+{
+    const size_t HW = (size_t)H * W;
+    const int chunks = orn_cdiv((long)HW, DY_PPB);
+    size_t f = 0;
+    f += orn_align((size_t)B * O * HW * 4) / 4;                         // dy
+    f += orn_align((size_t)O * C * 9 * 4) / 4;                          // Wd
+    f += orn_align((size_t)wgrad_split(B, C, O, H, W) * O * C * 9 * 4) / 4;   // wgrad partial slabs
+    f += orn_align((size_t)B * chunks * O * 4) / 4;                     // dbias partials
+    return f * 4;
+}
+
+int orn_launch_conv_bwd_f32(const float *x, const float *wf, const float *z, const float *da, int B, int C, int O,
+                            int H, int W, int s, float *dx, float *dwf, float *dbf, float *ws, hipStream_t st)
+{
+    const size_t HW = (size_t)H * W;
+    const int chunks = orn_cdiv((long)HW, DY_PPB);
+    const int S = wgrad_split(B, C, O, H, W);
+    float *dy = ws;
+    float *wd = dy + orn_align((size_t)B * O * HW * 4) / 4;
+    float *slabs = wd + orn_align((size_t)O * C * 9 * 4) / 4;
+    float *dbp = slabs + orn_align((size_t)S * O * C * 9 * 4) / 4;
+
+    hipLaunchKernelGGL(k_silu_bwd_unshuffle, dim3(chunks, O, B), dim3(256), 0, st, da, z, O, H, W, s, dy, dbp);
+    ORN_LAUNCH_CHECK("silu_bwd_unshuffle");
+    ORN_TRY(orn_launch_reduce_rows(dbp, B * chunks, (size_t)O, (size_t)O, dbf, st));
+
+    WgradP p;
+    p.x = x; p.dy = dy; p.partial = slabs;
+    p.B = B; p.C = C; p.O = O; p.H = H; p.W = W;
+    p.tiles_w = orn_cdiv(W, WG_TW); p.tiles_h = orn_cdiv(H, WG_TH);
+    p.n_ktiles = B * p.tiles_w * p.tiles_h;
+    p.S = S;
+    p.n_ntiles = orn_cdiv(C * 9, WG_BN);
+    hipLaunchKernelGGL(k_wgrad_f32, dim3(orn_cdiv(O, WG_BO) * p.n_ntiles, S), dim3(256), 0, st, p);
+    ORN_LAUNCH_CHECK("wgrad_f32");
+    ORN_TRY(orn_launch_reduce_rows(slabs, S, (size_t)O * C * 9, (size_t)O * C * 9, dwf, st));
+
+    if (dx) {
+        hipLaunchKernelGGL(k_flip_transpose_w, dim3(orn_cdiv((long)O * C * 9, 256)), dim3(256), 0, st, wf, O, C, wd);
+        ORN_LAUNCH_CHECK("flip_transpose_w");
+        ORN_TRY(orn_launch_conv3x3_f32(dy, wd, nullptr, B, O, C, H, W, 1, EPI_PLAIN, nullptr, dx, st));
+    }
+    return 0;
+}
+
+extern "C" int orn_conv3x3_ps_silu_bwd(const float *x, const float *wf, const float *z, const float *da, int B,
+                                       int C, int O, int H, int W, int s, float *dx, float *dwf, float *dbf,
+                                       void *ws, size_t ws_bytes, void *stream)
+{
+    ORN_REQUIRE(x && wf && z && da && dwf && dbf && ws, "conv3x3_ps_silu_bwd: null pointer");
+    ORN_REQUIRE(B > 0 && C > 0 && O > 0 && H > 0 && W > 0 && s > 0 && O % (s * s) == 0, "conv3x3_ps_silu_bwd: bad sizes");
+    if (ws_bytes < orn_conv3x3_ps_silu_bwd_ws_bytes(B, C, O, H, W)) {
+        orn_set_error("conv3x3_ps_silu_bwd: workspace %zu < %zu", ws_bytes, orn_conv3x3_ps_silu_bwd_ws_bytes(B, C, O, H, W));
+        return ORN_E_WS;
+    }
+    return orn_launch_conv_bwd_f32(x, wf, z, da, B, C, O, H, W, s, dx, dwf, dbf, (float *)ws, (hipStream_t)stream);
+}

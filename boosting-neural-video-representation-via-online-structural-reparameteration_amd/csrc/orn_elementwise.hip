@@ -1,0 +1,449 @@
+// Small HBM-/latency-bound kernels of the hot path: positional encoding (A1), MLP stem (A2),
+// 1x1 head (A5), Adam (A9) and the deterministic reduction helpers everything else shares.
+#include "orn_common.h"
+#include <math.h>
+#include <string.h>
+
+// ------------------------------------------------------------------------------------------------
+// error text (thread-local)
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void orn_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int orn_version(void) { return ORN_VERSION; }
+
+extern "C" int orn_last_error(char *buf, size_t n)
+{
+    if (!buf || n == 0) return (int)strlen(g_err);
+    strncpy(buf, g_err, n - 1);
+    buf[n - 1] = 0;
+    return (int)strlen(buf);
+}
+
+// ------------------------------------------------------------------------------------------------
+// reductions
+// ------------------------------------------------------------------------------------------------
+// out[j] = sum_i in[i*ld + j], i ascending (fixed order).
+__global__ void k_reduce_rows(const float *__restrict__ in, int rows, size_t ld, size_t n, float *__restrict__ out)
+{
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float acc = 0.f;
+    for (int i = 0; i < rows; ++i) acc += in[(size_t)i * ld + j];
+    out[j] = acc;
+}
+
+int orn_launch_reduce_rows(const float *in, int rows, size_t ld, size_t n, float *out, hipStream_t st)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_reduce_rows, dim3(orn_cdiv((long)n, 256)), dim3(256), 0, st, in, rows, ld, n, out);
+    ORN_LAUNCH_CHECK("reduce_rows");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A1  positional encoding                                                  utils.py:121-129
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pe_fwd(const float *__restrict__ pos, int B, const float *__restrict__ lbase_pow, int levels,
+                         float *__restrict__ out)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * levels) return;
+    const int b = idx / levels, i = idx % levels;
+    // fp32(fp32(pos * fp32(lbase^i)) * fp32(pi)); __fmul_rn blocks any contraction / reassociation.
+    const float arg = __fmul_rn(__fmul_rn(pos[b], lbase_pow[i]), 3.14159265358979323846f);
+    // accurate (range-reduced) sinf/cosf: arguments reach 1.9e4 rad, no __sinf here.
+    out[(size_t)b * 2 * levels + 2 * i] = sinf(arg);
+    out[(size_t)b * 2 * levels + 2 * i + 1] = cosf(arg);
+}
+
+extern "C" int orn_pe_fwd(const float *pos, int B, const float *lbase_pow, int levels, float *out, void *stream)
+{
+    ORN_REQUIRE(pos && lbase_pow && out && B > 0 && levels > 0, "pe_fwd: bad arguments");
+    hipLaunchKernelGGL(k_pe_fwd, dim3(orn_cdiv((long)B * levels, 128)), dim3(128), 0, (hipStream_t)stream, pos, B,
+                       lbase_pow, levels, out);
+    ORN_LAUNCH_CHECK("pe_fwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A2  stem                                                                 model.py:174-188
+// ------------------------------------------------------------------------------------------------
+// y[b][o] = silu(pre), pre = bias[o] + sum_k w[o][k]*x[b][k]; one wave per output neuron.
+// x row selected through an optional device index (engine: frame index of the current step).
+__global__ void k_linear_silu(const float *__restrict__ x, const int *__restrict__ row_idx, size_t row_stride,
+                              const float *__restrict__ w, const float *__restrict__ bias, int B, int K, int N,
+                              float *__restrict__ pre, float *__restrict__ y)
+{
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= N) return;
+    if (row_idx) x += (size_t)(*row_idx) * row_stride;
+    const float *wr = w + (size_t)wave * K;
+    for (int b = 0; b < B; ++b) {
+        float acc = 0.f;
+        for (int k = lane; k < K; k += 64) acc = fmaf(wr[k], x[(size_t)b * K + k], acc);
+        acc = orn_wave_sum(acc);
+        if (lane == 0) {
+            const float p = acc + bias[wave];
+            pre[(size_t)b * N + wave] = p;
+            y[(size_t)b * N + wave] = p / (1.0f + expf(-p));
+        }
+    }
+}
+
+int orn_launch_linear_silu(const float *x, const int *row_idx, size_t row_stride, const float *w, const float *b,
+                           int B, int K, int N, float *pre, float *y, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_linear_silu, dim3(orn_cdiv((long)N * 64, 256)), dim3(256), 0, st, x, row_idx, row_stride,
+                       w, b, B, K, N, pre, y);
+    ORN_LAUNCH_CHECK("linear_silu");
+    return 0;
+}
+
+extern "C" int orn_stem_fwd(const float *embed, const float *w0, const float *b0, const float *w1, const float *b1,
+                            int B, int E, int Hd, int Nout, float *pre1, float *h1, float *pre2, float *h2,
+                            void *stream)
+{
+    ORN_REQUIRE(embed && w0 && b0 && w1 && b1 && pre1 && h1 && pre2 && h2, "stem_fwd: null pointer");
+    ORN_REQUIRE(B > 0 && E > 0 && Hd > 0 && Nout > 0, "stem_fwd: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    ORN_TRY(orn_launch_linear_silu(embed, nullptr, 0, w0, b0, B, E, Hd, pre1, h1, st));
+    ORN_TRY(orn_launch_linear_silu(h1, nullptr, 0, w1, b1, B, Hd, Nout, pre2, h2, st));
+    return 0;
+}
+
+// dpre[b][o] = dy[b][o]*silu'(pre[b][o]);  db[o] = sum_b dpre;  dw[o][k] = sum_b dpre[b][o]*x[b][k]
+__global__ void k_linear_silu_bwd_w(const float *__restrict__ x, const int *__restrict__ row_idx, size_t row_stride,
+                                    const float *__restrict__ pre, const float *__restrict__ dy, int B, int K, int N,
+                                    float *__restrict__ dpre, float *__restrict__ dw, float *__restrict__ db)
+{
+    const int o = blockIdx.x;
+    if (row_idx) x += (size_t)(*row_idx) * row_stride;
+    float dsum = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float d = dy[(size_t)b * N + o] * orn_silu_grad_exact(pre[(size_t)b * N + o]);
+        dsum += d;
+        if (threadIdx.x == 0) dpre[(size_t)b * N + o] = d;
+    }
+    if (threadIdx.x == 0) db[o] = dsum;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float d = dy[(size_t)b * N + o] * orn_silu_grad_exact(pre[(size_t)b * N + o]);
+            acc = fmaf(d, x[(size_t)b * K + k], acc);
+        }
+        dw[(size_t)o * K + k] = acc;
+    }
+}
+
+// partial[chunk][b][k] = sum_{o in chunk} w[o][k]*dpre[b][o]
+__global__ void k_linear_bwd_x_partial(const float *__restrict__ w, const float *__restrict__ dpre, int B, int K,
+                                       int N, int rows_per_chunk, float *__restrict__ partial)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int chunk = blockIdx.y;
+    if (k >= K) return;
+    const int o0 = chunk * rows_per_chunk, o1 = min(N, o0 + rows_per_chunk);
+    for (int b = 0; b < B; ++b) {
+        float acc = 0.f;
+        for (int o = o0; o < o1; ++o) acc = fmaf(w[(size_t)o * K + k], dpre[(size_t)b * N + o], acc);
+        partial[((size_t)chunk * B + b) * K + k] = acc;
+    }
+}
+
+#define ORN_STEM_CHUNKS 64
+
+int orn_launch_stem_bwd(const float *embed, const int *row_idx, size_t row_stride, const float *w1, const float *pre1,
+                        const float *h1, const float *pre2, const float *dh2, int B, int E, int Hd, int Nout,
+                        float *dw0, float *db0, float *dw1, float *db1, float *ws, hipStream_t st)
+{
+    // ws: dpre2 [B*Nout] | dpre1 [B*Hd] | dh1 [B*Hd] | partial [CHUNKS*B*Hd]
+    float *dpre2 = ws;
+    float *dpre1 = dpre2 + (size_t)B * Nout;
+    float *dh1 = dpre1 + (size_t)B * Hd;
+    float *partial = dh1 + (size_t)B * Hd;
+    hipLaunchKernelGGL(k_linear_silu_bwd_w, dim3(Nout), dim3(256), 0, st, h1, nullptr, 0, pre2, dh2, B, Hd, Nout,
+                       dpre2, dw1, db1);
+    ORN_LAUNCH_CHECK("stem_bwd_w1");
+    const int rpc = orn_cdiv(Nout, ORN_STEM_CHUNKS);
+    hipLaunchKernelGGL(k_linear_bwd_x_partial, dim3(orn_cdiv(Hd, 128), ORN_STEM_CHUNKS), dim3(128), 0, st, w1, dpre2, B,
+                       Hd, Nout, rpc, partial);
+    ORN_LAUNCH_CHECK("stem_bwd_x");
+    ORN_TRY(orn_launch_reduce_rows(partial, ORN_STEM_CHUNKS, (size_t)B * Hd, (size_t)B * Hd, dh1, st));
+    hipLaunchKernelGGL(k_linear_silu_bwd_w, dim3(Hd), dim3(128), 0, st, embed, row_idx, row_stride, pre1, dh1, B, E, Hd,
+                       dpre1, dw0, db0);
+    ORN_LAUNCH_CHECK("stem_bwd_w0");
+    return 0;
+}
+
+size_t orn_stem_bwd_ws_floats(int B, int Hd, int Nout)
+{
+    return (size_t)B * Nout + 2 * (size_t)B * Hd + (size_t)ORN_STEM_CHUNKS * B * Hd;
+}
+
+extern "C" int orn_stem_bwd(const float *embed, const float *w1, const float *pre1, const float *h1,
+                            const float *pre2, const float *dh2, int B, int E, int Hd, int Nout, float *dw0,
+                            float *db0, float *dw1, float *db1, float *ws, void *stream)
+{
+    ORN_REQUIRE(embed && w1 && pre1 && h1 && pre2 && dh2 && dw0 && db0 && dw1 && db1 && ws, "stem_bwd: null pointer");
+    ORN_REQUIRE(B > 0 && E > 0 && Hd > 0 && Nout > 0, "stem_bwd: bad sizes");
+    return orn_launch_stem_bwd(embed, nullptr, 0, w1, pre1, h1, pre2, dh2, B, E, Hd, Nout, dw0, db0, dw1, db1, ws,
+                               (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// A5  head                                                                 model.py:621-622
+// ------------------------------------------------------------------------------------------------
+#define ORN_HEAD_MAXC 512
+
+template <int V>
+__global__ void k_head_fwd(const float *__restrict__ a, const float *__restrict__ w, const float *__restrict__ bias, int C,
+                           size_t HW, int sigmoid, float *__restrict__ out)
+{
+    __shared__ float sw[3 * ORN_HEAD_MAXC + 3];
+    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) sw[i] = w[i];
+    if (threadIdx.x < 3) sw[3 * C + threadIdx.x] = bias[threadIdx.x];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const size_t p = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (p >= HW) return;
+    const float *ab = a + (size_t)b * C * HW + p;
+    float acc[3][V];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[k][v] = 0.f;
+    for (int c = 0; c < C; ++c) {
+        float av[V];
+        if (V == 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(ab + (size_t)c * HW);
+            av[0] = t.x; av[1 % V] = t.y; av[2 % V] = t.z; av[3 % V] = t.w;
+        } else {
+            av[0] = ab[(size_t)c * HW];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[k][v] = fmaf(sw[k * C + c], av[v], acc[k][v]);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float r[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float u = acc[k][v] + sw[3 * C + k];
+            r[v] = sigmoid ? 1.0f / (1.0f + expf(-u)) : (tanhf(u) + 1.0f) * 0.5f;
+        }
+        float *o = out + ((size_t)b * 3 + k) * HW + p;
+        if (V == 4) *reinterpret_cast<float4 *>(o) = make_float4(r[0], r[1 % V], r[2 % V], r[3 % V]);
+        else o[0] = r[0];
+    }
+}
+
+int orn_launch_head_fwd(const float *a, const float *w, const float *b, int B, int C, size_t HW, int sigmoid,
+                        float *out, hipStream_t st)
+{
+    ORN_REQUIRE(C <= ORN_HEAD_MAXC, "head: C=%d > %d unsupported", C, ORN_HEAD_MAXC);
+    if (HW % 4 == 0)
+        hipLaunchKernelGGL(k_head_fwd<4>, dim3(orn_cdiv((long)HW / 4, 256), B), dim3(256), 0, st, a, w, b, C, HW, sigmoid, out);
+    else
+        hipLaunchKernelGGL(k_head_fwd<1>, dim3(orn_cdiv((long)HW, 256), B), dim3(256), 0, st, a, w, b, C, HW, sigmoid, out);
+    ORN_LAUNCH_CHECK("head_fwd");
+    return 0;
+}
+
+extern "C" int orn_head_fwd(const float *a, const float *w, const float *b, int B, int C, int H, int W, int sigmoid,
+                            float *out, void *stream)
+{
+    ORN_REQUIRE(a && w && b && out && B > 0 && C > 0 && H > 0 && W > 0, "head_fwd: bad arguments");
+    return orn_launch_head_fwd(a, w, b, B, C, (size_t)H * W, sigmoid, out, (hipStream_t)stream);
+}
+
+// Backward.  Block = 256 threads x PPT pixels of one batch item.  du kept in registers; per channel c:
+// da[c][p] = sum_k w[k][c]*du[k][p] (stored), s_k = sum_p du[k][p]*a[c][p] -> wave reduce -> LDS -> partial.
+// partial layout: [block][3*C + 3]  (dw[k][c] at k*C+c, db[k] at 3*C+k); reduced over blocks afterwards.
+#define ORN_HEAD_PPT 8
+__global__ void __launch_bounds__(256)
+k_head_bwd(const float *__restrict__ a, const float *__restrict__ w, const float *__restrict__ out,
+           const float *__restrict__ dout, int C, size_t HW, int sigmoid, float *__restrict__ da,
+           float *__restrict__ partial)
+{
+    __shared__ float sw[3 * ORN_HEAD_MAXC];
+    __shared__ float sred[4][3 * ORN_HEAD_MAXC + 3];
+    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) sw[i] = w[i];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t p0 = (size_t)blockIdx.x * 256 * ORN_HEAD_PPT;
+    float du[3][ORN_HEAD_PPT];
+    size_t pp[ORN_HEAD_PPT];
+#pragma unroll
+    for (int i = 0; i < ORN_HEAD_PPT; ++i) {
+        pp[i] = p0 + (size_t)i * 256 + threadIdx.x;
+        const bool ok = pp[i] < HW;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float d = 0.f;
+            if (ok) {
+                const float o = out[((size_t)b * 3 + k) * HW + pp[i]];
+                const float g = dout[((size_t)b * 3 + k) * HW + pp[i]];
+                // o = (tanh u + 1)/2 -> do/du = (1 - tanh^2)/2 = 2 o (1-o);  sigmoid: o (1-o)
+                d = g * (sigmoid ? o * (1.0f - o) : 2.0f * o * (1.0f - o));
+            }
+            du[k][i] = d;
+        }
+    }
+    float dbs[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < ORN_HEAD_PPT; ++i) s += du[k][i];
+        dbs[k] = orn_wave_sum(s);
+    }
+    if (lane == 0) {
+        sred[wave][3 * C + 0] = dbs[0];
+        sred[wave][3 * C + 1] = dbs[1];
+        sred[wave][3 * C + 2] = dbs[2];
+    }
+    for (int c = 0; c < C; ++c) {
+        const float w0 = sw[c], w1 = sw[C + c], w2 = sw[2 * C + c];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < ORN_HEAD_PPT; ++i) {
+            if (pp[i] < HW) {
+                const size_t idx = ((size_t)b * C + c) * HW + pp[i];
+                const float av = a[idx];
+                s0 = fmaf(du[0][i], av, s0);
+                s1 = fmaf(du[1][i], av, s1);
+                s2 = fmaf(du[2][i], av, s2);
+                da[idx] = fmaf(w2, du[2][i], fmaf(w1, du[1][i], w0 * du[0][i]));
+            }
+        }
+        s0 = orn_wave_sum(s0);
+        s1 = orn_wave_sum(s1);
+        s2 = orn_wave_sum(s2);
+        if (lane == 0) {
+            sred[wave][c] = s0;
+            sred[wave][C + c] = s1;
+            sred[wave][2 * C + c] = s2;
+        }
+    }
+    __syncthreads();
+    const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    for (int i = threadIdx.x; i < 3 * C + 3; i += blockDim.x)
+        partial[blk * (3 * C + 3) + i] = (sred[0][i] + sred[1][i]) + (sred[2][i] + sred[3][i]);
+}
+
+__global__ void k_head_split_dw(const float *__restrict__ red, int C, float *__restrict__ dw, float *__restrict__ db)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * C) dw[i] = red[i];
+    else if (i < 3 * C + 3) db[i - 3 * C] = red[i];
+}
+
+extern "C" size_t orn_head_bwd_ws_bytes(int B, int C, int H, int W)
+{
+    const size_t HW = (size_t)H * W;
+    const size_t nblk = (size_t)orn_cdiv((long)HW, 256 * ORN_HEAD_PPT) * B;
+    return orn_align((nblk + 1) * (3 * (size_t)C + 3) * sizeof(float));
+}
+
+int orn_launch_head_bwd(const float *a, const float *w, const float *out, const float *dout, int B, int C, size_t HW,
+                        int sigmoid, float *da, float *dw, float *db, float *ws, hipStream_t st)
+{
+    ORN_REQUIRE(C <= ORN_HEAD_MAXC, "head: C=%d > %d unsupported", C, ORN_HEAD_MAXC);
+    const int gx = orn_cdiv((long)HW, 256 * ORN_HEAD_PPT);
+    const size_t nblk = (size_t)gx * B, n = 3 * (size_t)C + 3;
+    float *partial = ws, *red = ws + nblk * n;
+    hipLaunchKernelGGL(k_head_bwd, dim3(gx, B), dim3(256), 0, st, a, w, out, dout, C, HW, sigmoid, da, partial);
+    ORN_LAUNCH_CHECK("head_bwd");
+    ORN_TRY(orn_launch_reduce_rows(partial, (int)nblk, n, n, red, st));
+    hipLaunchKernelGGL(k_head_split_dw, dim3(orn_cdiv((long)n, 128)), dim3(128), 0, st, red, C, dw, db);
+    ORN_LAUNCH_CHECK("head_split");
+    return 0;
+}
+
+extern "C" int orn_head_bwd(const float *a, const float *w, const float *out, const float *dout, int B, int C, int H,
+                            int W, int sigmoid, float *da, float *dw, float *db, void *ws, size_t ws_bytes,
+                            void *stream)
+{
+    ORN_REQUIRE(a && w && out && dout && da && dw && db && ws, "head_bwd: null pointer");
+    ORN_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "head_bwd: bad sizes");
+    if (ws_bytes < orn_head_bwd_ws_bytes(B, C, H, W)) {
+        orn_set_error("head_bwd: workspace %zu < %zu", ws_bytes, orn_head_bwd_ws_bytes(B, C, H, W));
+        return ORN_E_WS;
+    }
+    return orn_launch_head_bwd(a, w, out, dout, B, C, (size_t)H * W, sigmoid, da, dw, db, (float *)ws,
+                               (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// A9  Adam                                                                 main_train.py:196,250
+// ------------------------------------------------------------------------------------------------
+// hyper (device or by value): lr, step.  Matches torch.optim.Adam's algebra:
+//   m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                       size_t n, float lr_v, int step_v, const orn_step_sched *__restrict__ sp, float beta1, float beta2,
+                       float eps, float inv_gscale)
+{
+    float lr = lr_v;
+    int step = step_v;
+    if (sp) { lr = sp->lr; step = sp->step; }
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2 = 1.0f - powf(beta2, (float)step);
+    const float step_size = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+    const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    if (i0 + 4 <= n) {
+        float4 pv = *reinterpret_cast<float4 *>(p + i0);
+        const float4 gv = *reinterpret_cast<const float4 *>(g + i0);
+        float4 mv = *reinterpret_cast<float4 *>(m + i0);
+        float4 vv = *reinterpret_cast<float4 *>(v + i0);
+        float *pp = &pv.x, *mp = &mv.x, *vp = &vv.x;
+        const float *gp = &gv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gg = gp[k] * inv_gscale;
+            mp[k] = beta1 * mp[k] + (1.0f - beta1) * gg;
+            vp[k] = beta2 * vp[k] + (1.0f - beta2) * gg * gg;
+            pp[k] -= step_size * (mp[k] / (sqrtf(vp[k]) * inv_sqrt_bc2 + eps));
+        }
+        *reinterpret_cast<float4 *>(p + i0) = pv;
+        *reinterpret_cast<float4 *>(m + i0) = mv;
+        *reinterpret_cast<float4 *>(v + i0) = vv;
+    } else {
+        for (size_t i = i0; i < n; ++i) {
+            const float gg = g[i] * inv_gscale;
+            const float mm = beta1 * m[i] + (1.0f - beta1) * gg;
+            const float vv = beta2 * v[i] + (1.0f - beta2) * gg * gg;
+            m[i] = mm;
+            v[i] = vv;
+            p[i] -= step_size * (mm / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+        }
+    }
+}
+
+int orn_launch_adam(float *p, const float *g, float *m, float *v, size_t n, float lr, int step,
+                    const orn_step_sched *sp, float beta1, float beta2, float eps, float inv_gscale, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_adam, dim3(orn_cdiv((long)orn_cdiv((long)n, 4), 256)), dim3(256), 0, st, p, g, m, v, n, lr, step,
+                       sp, beta1, beta2, eps, inv_gscale);
+    ORN_LAUNCH_CHECK("adam");
+    return 0;
+}
+
+extern "C" int orn_adam_step(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1,
+                             float beta2, float eps, int step, void *stream)
+{
+    ORN_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
+    ORN_REQUIRE(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, "adam_step: arenas must be 16-byte aligned");
+    return orn_launch_adam(p, g, m, v, n, lr, step, nullptr, beta1, beta2, eps, 1.0f, (hipStream_t)stream);
+}

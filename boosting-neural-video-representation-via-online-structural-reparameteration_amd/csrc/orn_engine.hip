@@ -1,0 +1,289 @@
+// A11  The per-frame training step of main_train.py:229-254 as one native engine:
+//   stem -> N x {online ERB merge, conv3x3+PixelShuffle+SiLU} -> head -> loss (+PSNR) -> backward
+//   -> Adam, every launch on the caller's stream, capturable as one hipGraph.
+// The engine owns no device memory: four parameter-shaped arenas + one workspace come from the
+// caller (PyTorch is only the allocator).
+#include "orn_internal.h"
+#include <new>
+
+struct LayerBuf {
+    float *T, *wf, *bf;   // merge products (ERB) -- wf/bf alias the params for vanilla/deploy
+    float *z, *a;         // block output (pre-activation, activation)
+    float *da;            // gradient wrt the block output
+};
+
+struct orn_engine {
+    orn_engine_desc d;
+    float *params, *grads, *m, *v;
+    float *ws;
+    // workspace carve
+    float *pre1, *h1, *pre2, *h2, *dh2;
+    float *img, *dimg, *stats;
+    float *loss_ws;
+    float *scratch;                  // shared scratch for the backward kernels
+    orn_step_sched *cur;             // current step's schedule entry (device)
+    int32_t *cur_slot;               // ring slot of the current step (device)
+    LayerBuf L[ORN_MAX_LAYERS];
+    int Hout, Wout, Cn_last;
+    // graph cache (one captured train step)
+    hipGraph_t graph;
+    hipGraphExec_t graph_exec;
+    const void *g_frames, *g_embeds, *g_sched, *g_cursor, *g_stats;
+    int g_slots;
+    hipStream_t g_stream;
+};
+
+static inline size_t al(size_t floats) { return orn_align(floats * 4) / 4; }
+
+extern "C" size_t orn_conv3x3_ps_silu_bwd_ws_bytes(int B, int C, int O, int H, int W);
+extern "C" size_t orn_erb_merge_bwd_ws_bytes(int C, int O);
+extern "C" size_t orn_head_bwd_ws_bytes(int B, int C, int H, int W);
+extern "C" size_t orn_loss_ws_bytes(int B, int Ch, int H, int W);
+
+static int check_desc(const orn_engine_desc *d)
+{
+    ORN_REQUIRE(d, "engine: null desc");
+    ORN_REQUIRE(d->n_layers >= 1 && d->n_layers <= ORN_MAX_LAYERS, "engine: n_layers=%d out of range", d->n_layers);
+    ORN_REQUIRE(d->precision == 0, "engine: precision %d not built", d->precision);
+    ORN_REQUIRE(d->embed_len > 0 && d->stem_dim > 0 && d->fc_h > 0 && d->fc_w > 0 && d->fc_dim > 0, "engine: bad stem geometry");
+    int C = d->fc_dim, H = d->fc_h, W = d->fc_w;
+    for (int i = 0; i < d->n_layers; ++i) {
+        const orn_layer_desc &l = d->layer[i];
+        ORN_REQUIRE(l.C == C && l.H == H && l.W == W,
+                    "engine: layer %d geometry (C=%d,H=%d,W=%d) does not chain (expected %d,%d,%d)", i, l.C, l.H, l.W, C, H, W);
+        ORN_REQUIRE(l.s >= 1 && l.O > 0 && l.O % (l.s * l.s) == 0, "engine: layer %d: O=%d not divisible by s^2", i, l.O);
+        ORN_REQUIRE(l.w3x3 >= 0 && l.b3x3 >= 0, "engine: layer %d: missing 3x3 weight/bias", i);
+        if (d->erb)
+            ORN_REQUIRE(l.w3x1 >= 0 && l.b3x1 >= 0 && l.w1x3 >= 0 && l.b1x3 >= 0 && l.w1 >= 0 && l.w2 >= 0 && l.w3 >= 0,
+                        "engine: layer %d: missing ERB branch tensors", i);
+        C = l.O / (l.s * l.s); H *= l.s; W *= l.s;
+    }
+    ORN_REQUIRE(d->n_params > 0 && d->n_params % 4 == 0, "engine: n_params must be a positive multiple of 4");
+    ORN_REQUIRE(d->loss_type >= 0 && d->loss_type <= 2, "engine: bad loss_type %d", d->loss_type);
+    return 0;
+}
+
+// Computes the workspace layout (in floats); if e != null also fills its pointers.
+static size_t layout(const orn_engine_desc *d, orn_engine *e)
+{
+    size_t off = 0;
+    float *base = e ? e->ws : nullptr;
+    auto take = [&](size_t floats) { float *p = base ? base + off : nullptr; off += al(floats); return p; };
+    const int Nout = d->fc_h * d->fc_w * d->fc_dim;
+    float *pre1 = take(d->stem_dim), *h1 = take(d->stem_dim), *pre2 = take(Nout), *h2 = take(Nout), *dh2 = take(Nout);
+    size_t scratch = orn_stem_bwd_ws_floats(1, d->stem_dim, Nout);
+    LayerBuf L[ORN_MAX_LAYERS] = {};
+    int Cn = d->fc_dim, H = d->fc_h, W = d->fc_w;
+    for (int i = 0; i < d->n_layers; ++i) {
+        const orn_layer_desc &l = d->layer[i];
+        const size_t wsz = (size_t)l.O * l.C * 9;
+        if (d->erb) { L[i].T = take(wsz); L[i].wf = take(wsz); L[i].bf = take(l.O); }
+        Cn = l.O / (l.s * l.s); H = l.H * l.s; W = l.W * l.s;
+        const size_t asz = (size_t)Cn * H * W;
+        L[i].z = take(asz); L[i].a = take(asz); L[i].da = take(asz);
+        size_t s1 = orn_conv3x3_ps_silu_bwd_ws_bytes(1, l.C, l.O, l.H, l.W) / 4;
+        if (d->erb) { const size_t s2 = orn_erb_merge_bwd_ws_bytes(l.C, l.O) / 4; if (s2 > s1) s1 = s2; }
+        if (s1 > scratch) scratch = s1;
+    }
+    const size_t isz = (size_t)3 * H * W;
+    float *img = take(isz), *dimg = take(isz), *stats = take(8);
+    float *loss_ws = take(orn_loss_ws_bytes(1, 3, H, W) / 4);
+    const size_t s3 = orn_head_bwd_ws_bytes(1, Cn, H, W) / 4;
+    if (s3 > scratch) scratch = s3;
+    float *scr = take(scratch);
+    float *cur = take(8);
+    if (e) {
+        e->pre1 = pre1; e->h1 = h1; e->pre2 = pre2; e->h2 = h2; e->dh2 = dh2;
+        e->img = img; e->dimg = dimg; e->stats = stats; e->loss_ws = loss_ws; e->scratch = scr;
+        e->cur = (orn_step_sched *)cur; e->cur_slot = (int32_t *)(cur + 4);
+        for (int i = 0; i < d->n_layers; ++i) e->L[i] = L[i];
+        e->Hout = H; e->Wout = W; e->Cn_last = Cn;
+    }
+    return off * 4;
+}
+
+extern "C" size_t orn_engine_ws_bytes(const orn_engine_desc *d)
+{
+    if (check_desc(d) != 0) return 0;
+    return layout(d, nullptr);
+}
+
+extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float *grads, float *adam_m, float *adam_v,
+                                 void *ws, size_t ws_bytes, orn_engine **out)
+{
+    ORN_TRY(check_desc(d));
+    ORN_REQUIRE(params && out && ws, "engine_create: null pointer");
+    ORN_REQUIRE(((uintptr_t)params | (uintptr_t)grads | (uintptr_t)adam_m | (uintptr_t)adam_v | (uintptr_t)ws) % 256 == 0,
+                "engine_create: arenas and workspace must be 256-byte aligned");
+    const size_t need = layout(d, nullptr);
+    if (ws_bytes < need) {
+        orn_set_error("engine_create: workspace %zu < %zu", ws_bytes, need);
+        return ORN_E_WS;
+    }
+    ORN_TRY(orn_loss_init());
+    orn_engine *e = new (std::nothrow) orn_engine();
+    ORN_REQUIRE(e, "engine_create: out of host memory");
+    e->d = *d;
+    e->params = params; e->grads = grads; e->m = adam_m; e->v = adam_v;
+    e->ws = (float *)ws;
+    e->graph = nullptr; e->graph_exec = nullptr;
+    layout(d, e);
+    if (!d->erb)
+        for (int i = 0; i < d->n_layers; ++i) {
+            e->L[i].T = nullptr;
+            e->L[i].wf = params + d->layer[i].w3x3;
+            e->L[i].bf = params + d->layer[i].b3x3;
+        }
+    *out = e;
+    return 0;
+}
+
+extern "C" void orn_engine_destroy(orn_engine *e)
+{
+    if (!e) return;
+    if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
+    if (e->graph) (void)hipGraphDestroy(e->graph);
+    delete e;
+}
+
+extern "C" int orn_engine_fused_kernel(orn_engine *e, int layer, const float **wf, const float **bf)
+{
+    ORN_REQUIRE(e && wf && bf && layer >= 0 && layer < e->d.n_layers, "engine_fused_kernel: bad arguments");
+    *wf = e->L[layer].wf;
+    *bf = e->L[layer].bf;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_advance(const orn_step_sched *__restrict__ sched, int32_t *cursor, int32_t n_slots,
+                          orn_step_sched *cur, int32_t *cur_slot)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int32_t c = *cursor;
+        *cur = sched[c];
+        *cur_slot = n_slots > 0 ? c % n_slots : 0;
+        *cursor = c + 1;
+    }
+}
+
+__global__ void k_publish_stats(const float *__restrict__ stats, const orn_step_sched *cur, const int32_t *cur_slot,
+                                float *ring)
+{
+    const int t = threadIdx.x;
+    if (t < 8) {
+        float v = stats[t];
+        if (t == 5) v = cur->lr;
+        if (t == 6) v = (float)cur->frame;
+        if (t == 7) v = (float)cur->step;
+        ring[(size_t)(*cur_slot) * 8 + t] = v;
+    }
+}
+
+static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool keep_z, hipStream_t st)
+{
+    const orn_engine_desc &d = e->d;
+    const int Nout = d.fc_h * d.fc_w * d.fc_dim;
+    float *P = e->params;
+    ORN_TRY(orn_launch_linear_silu(embeds, row_idx, d.embed_len, P + d.stem_w0, P + d.stem_b0, 1, d.embed_len, d.stem_dim,
+                                   e->pre1, e->h1, st));
+    ORN_TRY(orn_launch_linear_silu(e->h1, nullptr, 0, P + d.stem_w1, P + d.stem_b1, 1, d.stem_dim, Nout, e->pre2, e->h2, st));
+    const float *x = e->h2;
+    for (int i = 0; i < d.n_layers; ++i) {
+        const orn_layer_desc &l = d.layer[i];
+        LayerBuf &b = e->L[i];
+        if (d.erb)
+            ORN_TRY(orn_launch_merge_fwd(P + l.w3x3, P + l.b3x3, P + l.w3x1, P + l.b3x1, P + l.w1x3, P + l.b1x3, P + l.w1,
+                                         P + l.w2, P + l.w3, l.C, l.O, b.T, b.wf, b.bf, st));
+        ORN_TRY(orn_launch_conv3x3_f32(x, b.wf, b.bf, 1, l.C, l.O, l.H, l.W, l.s, 1, keep_z ? b.z : nullptr, b.a, st));
+        x = b.a;
+    }
+    ORN_TRY(orn_launch_head_fwd(x, P + d.head_w, P + d.head_b, 1, e->Cn_last, (size_t)e->Hout * e->Wout, d.sigmoid, e->img, st));
+    return 0;
+}
+
+extern "C" int orn_engine_decode(orn_engine *e, const float *embed, float *img, void *stream)
+{
+    ORN_REQUIRE(e && embed && img, "engine_decode: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    ORN_TRY(forward(e, embed, nullptr, false, st));
+    hipError_t rc = hipMemcpyAsync(img, e->img, (size_t)3 * e->Hout * e->Wout * 4, hipMemcpyDeviceToDevice, st);
+    if (rc != hipSuccess) { orn_set_error("engine_decode: copy failed: %s", hipGetErrorString(rc)); return (int)rc; }
+    return 0;
+}
+
+static int train_step(orn_engine *e, const float *frames, const float *embeds, const orn_step_sched *sched,
+                      int32_t *cursor, float *stats_out, int32_t n_slots, hipStream_t st)
+{
+    const orn_engine_desc &d = e->d;
+    float *P = e->params, *G = e->grads;
+    const int Nout = d.fc_h * d.fc_w * d.fc_dim;
+    const size_t HWo = (size_t)e->Hout * e->Wout;
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, sched, cursor, n_slots, e->cur, e->cur_slot);
+    ORN_LAUNCH_CHECK("advance");
+    const int *fidx = &e->cur->frame;
+    ORN_TRY(forward(e, embeds, fidx, true, st));
+    ORN_TRY(orn_launch_loss(e->img, frames, fidx, 3 * HWo, 1, 3, e->Hout, e->Wout, d.loss_type, 1.0f, e->stats, e->dimg,
+                            e->loss_ws, st));
+    if (stats_out) {
+        hipLaunchKernelGGL(k_publish_stats, dim3(1), dim3(64), 0, st, e->stats, e->cur, e->cur_slot, stats_out);
+        ORN_LAUNCH_CHECK("publish_stats");
+    }
+    const int nl = d.n_layers;
+    ORN_TRY(orn_launch_head_bwd(e->L[nl - 1].a, P + d.head_w, e->img, e->dimg, 1, e->Cn_last, HWo, d.sigmoid, e->L[nl - 1].da,
+                                G + d.head_w, G + d.head_b, e->scratch, st));
+    for (int i = nl - 1; i >= 0; --i) {
+        const orn_layer_desc &l = d.layer[i];
+        LayerBuf &b = e->L[i];
+        const float *x = (i == 0) ? e->h2 : e->L[i - 1].a;
+        float *dx = (i == 0) ? e->dh2 : e->L[i - 1].da;
+        // dWf / dbf land directly in the 3x3 branch's gradient slots (dW3x3 = dWf, db3x3 = dbf)
+        ORN_TRY(orn_launch_conv_bwd_f32(x, b.wf, b.z, b.da, 1, l.C, l.O, l.H, l.W, l.s, dx, G + l.w3x3, G + l.b3x3, e->scratch, st));
+        if (d.erb)
+            ORN_TRY(orn_launch_merge_bwd(G + l.w3x3, G + l.b3x3, P + l.w1, P + l.w2, P + l.w3, b.T, l.C, l.O, G + l.w3x3,
+                                         G + l.b3x3, G + l.w3x1, G + l.b3x1, G + l.w1x3, G + l.b1x3, G + l.w1, G + l.w2,
+                                         G + l.w3, e->scratch, st));
+    }
+    ORN_TRY(orn_launch_stem_bwd(embeds, fidx, d.embed_len, P + d.stem_w1, e->pre1, e->h1, e->pre2, e->dh2, 1, d.embed_len,
+                                d.stem_dim, Nout, G + d.stem_w0, G + d.stem_b0, G + d.stem_w1, G + d.stem_b1, e->scratch, st));
+    ORN_TRY(orn_launch_adam(P, G, e->m, e->v, (size_t)d.n_params, 0.f, 1, e->cur, d.beta1, d.beta2, d.eps, 1.0f, st));
+    return 0;
+}
+
+extern "C" int orn_engine_train_step(orn_engine *e, const float *frames, const float *embeds,
+                                     const orn_step_sched *sched, int32_t *cursor, float *stats_out, int32_t n_slots,
+                                     void *stream)
+{
+    ORN_REQUIRE(e && frames && embeds && sched && cursor, "engine_train_step: null pointer");
+    ORN_REQUIRE(e->grads && e->m && e->v, "engine_train_step: engine was created without grads / Adam arenas");
+    return train_step(e, frames, embeds, sched, cursor, stats_out, n_slots, (hipStream_t)stream);
+}
+
+extern "C" int orn_engine_train_steps_graph(orn_engine *e, const float *frames, const float *embeds,
+                                            const orn_step_sched *sched, int32_t *cursor, float *stats_out,
+                                            int32_t n_slots, int32_t n_steps, void *stream)
+{
+    ORN_REQUIRE(e && frames && embeds && sched && cursor && n_steps >= 0, "engine_train_steps_graph: bad arguments");
+    ORN_REQUIRE(e->grads && e->m && e->v, "engine_train_steps_graph: engine was created without grads / Adam arenas");
+    hipStream_t st = (hipStream_t)stream;
+    const bool same = e->graph_exec && e->g_frames == frames && e->g_embeds == embeds && e->g_sched == sched &&
+                      e->g_cursor == cursor && e->g_stats == stats_out && e->g_slots == n_slots && e->g_stream == st;
+    if (!same) {
+        if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+        if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
+        hipError_t rc = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (rc != hipSuccess) { orn_set_error("graph: BeginCapture failed: %s", hipGetErrorString(rc)); return (int)rc; }
+        const int trc = train_step(e, frames, embeds, sched, cursor, stats_out, n_slots, st);
+        rc = hipStreamEndCapture(st, &e->graph);
+        if (trc != 0) { if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; } return trc; }
+        if (rc != hipSuccess) { orn_set_error("graph: EndCapture failed: %s", hipGetErrorString(rc)); return (int)rc; }
+        rc = hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0);
+        if (rc != hipSuccess) { orn_set_error("graph: Instantiate failed: %s", hipGetErrorString(rc)); return (int)rc; }
+        e->g_frames = frames; e->g_embeds = embeds; e->g_sched = sched; e->g_cursor = cursor; e->g_stats = stats_out;
+        e->g_slots = n_slots; e->g_stream = st;
+    }
+    for (int i = 0; i < n_steps; ++i) {
+        hipError_t rc = hipGraphLaunch(e->graph_exec, st);
+        if (rc != hipSuccess) { orn_set_error("graph: Launch failed: %s", hipGetErrorString(rc)); return (int)rc; }
+    }
+    return 0;
+}

@@ -1,0 +1,37 @@
+// Internal (non-exported) launchers shared between the op files and the engine.
+#pragma once
+#include "orn_common.h"
+
+// orn_elementwise.hip
+int orn_launch_linear_silu(const float *x, const int *row_idx, size_t row_stride, const float *w, const float *b,
+                           int B, int K, int N, float *pre, float *y, hipStream_t st);
+int orn_launch_stem_bwd(const float *embed, const int *row_idx, size_t row_stride, const float *w1, const float *pre1,
+                        const float *h1, const float *pre2, const float *dh2, int B, int E, int Hd, int Nout,
+                        float *dw0, float *db0, float *dw1, float *db1, float *ws, hipStream_t st);
+size_t orn_stem_bwd_ws_floats(int B, int Hd, int Nout);
+int orn_launch_head_fwd(const float *a, const float *w, const float *b, int B, int C, size_t HW, int sigmoid,
+                        float *out, hipStream_t st);
+int orn_launch_head_bwd(const float *a, const float *w, const float *out, const float *dout, int B, int C, size_t HW,
+                        int sigmoid, float *da, float *dw, float *db, float *ws, hipStream_t st);
+int orn_launch_adam(float *p, const float *g, float *m, float *v, size_t n, float lr, int step,
+                    const orn_step_sched *sp, float beta1, float beta2, float eps, float inv_gscale, hipStream_t st);
+
+// orn_merge.hip
+int orn_launch_merge_fwd(const float *w3x3, const float *b3x3, const float *w3x1, const float *b3x1,
+                         const float *w1x3, const float *b1x3, const float *w1, const float *w2, const float *w3,
+                         int C, int O, float *T, float *wf, float *bf, hipStream_t st);
+int orn_launch_merge_bwd(const float *g, const float *dbf, const float *w1, const float *w2, const float *w3,
+                         const float *T, int C, int O, float *d3x3, float *db3x3, float *d3x1, float *db3x1,
+                         float *d1x3, float *db1x3, float *dw1, float *dw2, float *dw3, float *ws, hipStream_t st);
+
+// orn_conv_f32.hip
+int orn_launch_conv3x3_f32(const float *x, const float *w, const float *bias, int B, int C, int O, int H, int W,
+                           int s, int epi, float *z, float *out, hipStream_t st);
+int orn_launch_conv_bwd_f32(const float *x, const float *wf, const float *z, const float *da, int B, int C, int O,
+                            int H, int W, int s, float *dx, float *dwf, float *dbf, float *ws, hipStream_t st);
+
+// orn_loss.hip
+int orn_loss_init();
+int orn_launch_loss(const float *pred, const float *target, const int *frame_idx, size_t frame_stride, int B, int Ch,
+                    int H, int W, int loss_type, float loss_scale, float *stats, float *dpred, float *ws,
+                    hipStream_t st);

@@ -1,0 +1,302 @@
+// A7 + A10  loss_fn (utils.py:139-189: L2, L1, Fusion6 = 0.7*L1 + 0.3*(1-SSIM)) fused with its
+// gradient and with psnr_fn (utils.py:191-199).  HBM-bound on 11 MB planes; two tiled passes:
+//   k_ssim_stats : 11-tap separable Gaussian (sigma 1.5, valid) of p, t, p^2, t^2, pt in LDS ->
+//                  SSIM map value (summed) and dS/dm, dS/dq, dS/dr maps
+//   k_loss_grad  : adjoint (full) filter of the three maps + L1/L2 terms -> dL/dpred, |p-t| and
+//                  (p-t)^2 sums
+// followed by a fixed-order finalize.  SSIM follows pytorch_msssim 0.2.1's published algorithm
+// (the package is not in the reference tree: parity unpinned, see oracle/cpu_ref.py).
+#include "orn_common.h"
+
+#define SS_TH 16
+#define SS_TW 64
+#define SS_PH (SS_TH + 10)
+#define SS_PW (SS_TW + 10)
+
+__constant__ float c_gauss[11];
+
+struct LossP {
+    const float *pred, *target;
+    const int *frame_idx;      // optional device index selecting the target frame
+    size_t frame_stride;
+    int planes, H, W, Hv, Wv;  // planes = B*Ch
+    float *dm, *dq, *dr;       // [planes][Hv][Wv]
+    float *part_ssim;          // [n_blocks_ssim]
+    float *part_l1;            // [n_blocks_grad][2]
+    float *dpred;              // may be null
+    int loss_type;
+    float g_l1, g_l2, g_ssim;  // gradient scales (already include loss_scale and 1/n)
+    int tiles_w_v, tiles_h_v, tiles_w, tiles_h;
+};
+
+__global__ void __launch_bounds__(256) k_ssim_stats(LossP q)
+{
+    __shared__ float Ps[SS_PH][SS_PW];
+    __shared__ float Ts[SS_PH][SS_PW];
+    __shared__ float Hs[5][SS_PH][SS_TW];
+    __shared__ float sred[16];
+    const int t = threadIdx.x;
+    const int plane = blockIdx.y;
+    const int tw = blockIdx.x % q.tiles_w_v, th = blockIdx.x / q.tiles_w_v;
+    const int y0 = th * SS_TH, x0 = tw * SS_TW;         // valid-map coords == image coords of the window origin
+    const size_t HW = (size_t)q.H * q.W;
+    const float *pp = q.pred + (size_t)plane * HW;
+    const float *tp = q.target + (q.frame_idx ? (size_t)(*q.frame_idx) * q.frame_stride : 0) + (size_t)plane * HW;
+    for (int idx = t; idx < SS_PH * SS_PW; idx += 256) {
+        const int r = idx / SS_PW, c = idx - r * SS_PW;
+        const int gy = y0 + r, gx = x0 + c;
+        float a = 0.f, b = 0.f;
+        if (gy < q.H && gx < q.W) { a = pp[(size_t)gy * q.W + gx]; b = tp[(size_t)gy * q.W + gx]; }
+        Ps[r][c] = a;
+        Ts[r][c] = b;
+    }
+    __syncthreads();
+    for (int idx = t; idx < SS_PH * SS_TW; idx += 256) {
+        const int r = idx / SS_TW, c = idx - r * SS_TW;
+        float sp = 0.f, st = 0.f, spp = 0.f, stt = 0.f, spt = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float g = c_gauss[k], a = Ps[r][c + k], b = Ts[r][c + k];
+            sp = fmaf(g, a, sp);
+            st = fmaf(g, b, st);
+            spp = fmaf(g, a * a, spp);
+            stt = fmaf(g, b * b, stt);
+            spt = fmaf(g, a * b, spt);
+        }
+        Hs[0][r][c] = sp; Hs[1][r][c] = st; Hs[2][r][c] = spp; Hs[3][r][c] = stt; Hs[4][r][c] = spt;
+    }
+    __syncthreads();
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    float ssum = 0.f;
+    for (int idx = t; idx < SS_TH * SS_TW; idx += 256) {
+        const int r = idx / SS_TW, c = idx - r * SS_TW;
+        const int gy = y0 + r, gx = x0 + c;
+        if (gy >= q.Hv || gx >= q.Wv) continue;
+        float m = 0.f, mu = 0.f, qq = 0.f, tt = 0.f, rr = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float g = c_gauss[k];
+            m = fmaf(g, Hs[0][r + k][c], m);
+            mu = fmaf(g, Hs[1][r + k][c], mu);
+            qq = fmaf(g, Hs[2][r + k][c], qq);
+            tt = fmaf(g, Hs[3][r + k][c], tt);
+            rr = fmaf(g, Hs[4][r + k][c], rr);
+        }
+        const float sp = qq - m * m, st = tt - mu * mu, spt = rr - m * mu;
+        const float A1 = 2.f * m * mu + C1, A2 = 2.f * spt + C2;
+        const float B1 = m * m + mu * mu + C1, B2 = sp + st + C2;
+        const float inv = 1.0f / (B1 * B2);
+        const float S = A1 * A2 * inv;
+        ssum += S;
+        const size_t o = ((size_t)plane * q.Hv + gy) * q.Wv + gx;
+        q.dm[o] = 2.f * mu * (A2 - A1) * inv - 2.f * m * S / B1 + 2.f * m * S / B2;
+        q.dq[o] = -S / B2;
+        q.dr[o] = 2.f * A1 * inv;
+    }
+    const float tot = orn_block_sum(ssum, sred);
+    if (t == 0) q.part_ssim[(size_t)plane * gridDim.x + blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(256) k_loss_grad(LossP q)
+{
+    __shared__ float Ds[3][SS_PH][SS_PW];
+    __shared__ float Hh[3][SS_PH][SS_TW];
+    __shared__ float sred[16];
+    const int t = threadIdx.x;
+    const int plane = blockIdx.y;
+    const int tw = blockIdx.x % q.tiles_w, th = blockIdx.x / q.tiles_w;
+    const int y0 = th * SS_TH, x0 = tw * SS_TW;
+    const size_t HW = (size_t)q.H * q.W;
+    const float *pp = q.pred + (size_t)plane * HW;
+    const float *tp = q.target + (q.frame_idx ? (size_t)(*q.frame_idx) * q.frame_stride : 0) + (size_t)plane * HW;
+    const bool ssim = (q.loss_type == ORN_LOSS_FUSION6);
+    if (ssim) {
+        const size_t mo = (size_t)plane * q.Hv * q.Wv;
+        for (int idx = t; idx < SS_PH * SS_PW; idx += 256) {
+            const int r = idx / SS_PW, c = idx - r * SS_PW;
+            const int vy = y0 + r - 10, vx = x0 + c - 10;       // valid-map coords
+            float a = 0.f, b = 0.f, d = 0.f;
+            if (vy >= 0 && vy < q.Hv && vx >= 0 && vx < q.Wv) {
+                const size_t o = mo + (size_t)vy * q.Wv + vx;
+                a = q.dm[o]; b = q.dq[o]; d = q.dr[o];
+            }
+            Ds[0][r][c] = a; Ds[1][r][c] = b; Ds[2][r][c] = d;
+        }
+        __syncthreads();
+        // out[y][x] = sum_{a,b} g[a] g[b] D[y-a][x-b];  patch index of (y-a) is (y_local + 10 - a)
+        for (int idx = t; idx < SS_PH * SS_TW; idx += 256) {
+            const int r = idx / SS_TW, c = idx - r * SS_TW;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const float g = c_gauss[k];
+                s0 = fmaf(g, Ds[0][r][c + 10 - k], s0);
+                s1 = fmaf(g, Ds[1][r][c + 10 - k], s1);
+                s2 = fmaf(g, Ds[2][r][c + 10 - k], s2);
+            }
+            Hh[0][r][c] = s0; Hh[1][r][c] = s1; Hh[2][r][c] = s2;
+        }
+        __syncthreads();
+    }
+    float sabs = 0.f, ssq = 0.f;
+    for (int idx = t; idx < SS_TH * SS_TW; idx += 256) {
+        const int r = idx / SS_TW, c = idx - r * SS_TW;
+        const int gy = y0 + r, gx = x0 + c;
+        if (gy >= q.H || gx >= q.W) continue;
+        const size_t o = (size_t)gy * q.W + gx;
+        const float p = pp[o], tg = tp[o], d = p - tg;
+        sabs += fabsf(d);
+        ssq = fmaf(d, d, ssq);
+        if (q.dpred) {
+            float g = 0.f;
+            if (q.loss_type == ORN_LOSS_L2) g = q.g_l2 * d;
+            else g = q.g_l1 * ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
+            if (ssim) {
+                float am = 0.f, aq = 0.f, ar = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; ++k) {
+                    const float gk = c_gauss[k];
+                    am = fmaf(gk, Hh[0][r + 10 - k][c], am);
+                    aq = fmaf(gk, Hh[1][r + 10 - k][c], aq);
+                    ar = fmaf(gk, Hh[2][r + 10 - k][c], ar);
+                }
+                g -= q.g_ssim * (am + 2.f * p * aq + tg * ar);
+            }
+            q.dpred[(size_t)plane * HW + o] = g;
+        }
+    }
+    const float ta = orn_block_sum(sabs, sred);
+    const float tq = orn_block_sum(ssq, sred);
+    if (t == 0) {
+        const size_t bi = (size_t)plane * gridDim.x + blockIdx.x;
+        q.part_l1[2 * bi] = ta;
+        q.part_l1[2 * bi + 1] = tq;
+    }
+}
+
+// One block; fixed-order strided partial sums in double, then a fixed tree.
+__global__ void __launch_bounds__(256)
+k_loss_finalize(const float *__restrict__ part_ssim, int n_ssim, const float *__restrict__ part_l1, int n_l1,
+                double n_elem, double n_map, int loss_type, float loss_scale, float *__restrict__ stats)
+{
+    __shared__ double sd[3][256];
+    const int t = threadIdx.x;
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int i = t; i < n_l1; i += 256) { a += (double)part_l1[2 * i]; b += (double)part_l1[2 * i + 1]; }
+    for (int i = t; i < n_ssim; i += 256) c += (double)part_ssim[i];
+    sd[0][t] = a; sd[1][t] = b; sd[2][t] = c;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) { sd[0][t] += sd[0][t + s]; sd[1][t] += sd[1][t + s]; sd[2][t] += sd[2][t + s]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const float l1 = (float)(sd[0][0] / n_elem);
+        const float mse = (float)(sd[1][0] / n_elem);
+        const float ss = (loss_type == ORN_LOSS_FUSION6) ? (float)(sd[2][0] / n_map) : 0.f;
+        float loss;
+        if (loss_type == ORN_LOSS_L2) loss = mse;
+        else if (loss_type == ORN_LOSS_L1) loss = l1;
+        else loss = 0.7f * l1 + 0.3f * (1.0f - ss);
+        stats[0] = loss * loss_scale;
+        stats[1] = l1;
+        stats[2] = mse;
+        stats[3] = ss;
+        stats[4] = -10.0f * log10f(mse);
+        stats[5] = 0.f; stats[6] = 0.f; stats[7] = 0.f;
+    }
+}
+
+static bool g_gauss_ready = false;
+
+static int ensure_gauss()
+{
+    if (g_gauss_ready) return 0;
+    // pytorch_msssim _fspecial_gauss_1d(11, 1.5): fp32 exp, fp32 normalise
+    float g[11], s = 0.f;
+    for (int i = 0; i < 11; ++i) {
+        const float c = (float)(i - 5);
+        g[i] = expf(-(c * c) / (2.0f * 1.5f * 1.5f));
+        s += g[i];
+    }
+    for (int i = 0; i < 11; ++i) g[i] /= s;
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_gauss), g, sizeof(g));
+    if (e != hipSuccess) {
+        orn_set_error("loss: hipMemcpyToSymbol failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    g_gauss_ready = true;
+    return 0;
+}
+
+// Must be called once outside any graph capture (hipMemcpyToSymbol is synchronous).
+int orn_loss_init() { return ensure_gauss(); }
+
+struct LossGeom { int planes, Hv, Wv, twv, thv, tw, th; size_t nmap, off_dq, off_dr, off_ps, off_pl, total; };
+
+static LossGeom loss_geom(int B, int Ch, int H, int W)
+{
+    LossGeom g;
+    g.planes = B * Ch;
+    g.Hv = H > 10 ? H - 10 : 0;
+    g.Wv = W > 10 ? W - 10 : 0;
+    g.twv = orn_cdiv(g.Wv, SS_TW); g.thv = orn_cdiv(g.Hv, SS_TH);
+    g.tw = orn_cdiv(W, SS_TW); g.th = orn_cdiv(H, SS_TH);
+    g.nmap = (size_t)g.planes * g.Hv * g.Wv;
+    const size_t a = orn_align(g.nmap * 4) / 4;
+    g.off_dq = a; g.off_dr = 2 * a;
+    g.off_ps = 3 * a;
+    g.off_pl = g.off_ps + orn_align((size_t)g.planes * g.twv * g.thv * 4 + 4) / 4;
+    g.total = g.off_pl + orn_align((size_t)g.planes * g.tw * g.th * 8 + 8) / 4;
+    return g;
+}
+
+extern "C" size_t orn_loss_ws_bytes(int B, int Ch, int H, int W) { return loss_geom(B, Ch, H, W).total * 4; }
+
+int orn_launch_loss(const float *pred, const float *target, const int *frame_idx, size_t frame_stride, int B, int Ch,
+                    int H, int W, int loss_type, float loss_scale, float *stats, float *dpred, float *ws,
+                    hipStream_t st)
+{
+    ORN_REQUIRE(loss_type == ORN_LOSS_L2 || loss_type == ORN_LOSS_L1 || loss_type == ORN_LOSS_FUSION6,
+                "loss: unsupported loss_type %d", loss_type);
+    ORN_TRY(ensure_gauss());
+    const LossGeom g = loss_geom(B, Ch, H, W);
+    if (loss_type == ORN_LOSS_FUSION6) ORN_REQUIRE(g.Hv > 0 && g.Wv > 0, "loss: SSIM needs H,W > 10 (got %dx%d)", H, W);
+    LossP q;
+    q.pred = pred; q.target = target; q.frame_idx = frame_idx; q.frame_stride = frame_stride;
+    q.planes = g.planes; q.H = H; q.W = W; q.Hv = g.Hv; q.Wv = g.Wv;
+    q.dm = ws; q.dq = ws + g.off_dq; q.dr = ws + g.off_dr;
+    q.part_ssim = ws + g.off_ps; q.part_l1 = ws + g.off_pl;
+    q.dpred = dpred; q.loss_type = loss_type;
+    const double n = (double)g.planes * H * W;
+    q.g_l1 = (float)((loss_type == ORN_LOSS_FUSION6 ? 0.7 : 1.0) * loss_scale / n);
+    q.g_l2 = (float)(2.0 * loss_scale / n);
+    q.g_ssim = g.nmap ? (float)(0.3 * loss_scale / (double)g.nmap) : 0.f;
+    q.tiles_w_v = g.twv; q.tiles_h_v = g.thv; q.tiles_w = g.tw; q.tiles_h = g.th;
+    int n_ssim = 0;
+    if (loss_type == ORN_LOSS_FUSION6) {
+        n_ssim = g.planes * g.twv * g.thv;
+        hipLaunchKernelGGL(k_ssim_stats, dim3(g.twv * g.thv, g.planes), dim3(256), 0, st, q);
+        ORN_LAUNCH_CHECK("ssim_stats");
+    }
+    hipLaunchKernelGGL(k_loss_grad, dim3(g.tw * g.th, g.planes), dim3(256), 0, st, q);
+    ORN_LAUNCH_CHECK("loss_grad");
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, st, q.part_ssim, n_ssim, q.part_l1, g.planes * g.tw * g.th, n,
+                       (double)g.nmap, loss_type, loss_scale, stats);
+    ORN_LAUNCH_CHECK("loss_finalize");
+    return 0;
+}
+
+extern "C" int orn_loss_fwd_bwd(const float *pred, const float *target, int B, int Ch, int H, int W, int loss_type,
+                                float loss_scale, float *stats, float *dpred, void *ws, size_t ws_bytes,
+                                void *stream)
+{
+    ORN_REQUIRE(pred && target && stats && ws, "loss_fwd_bwd: null pointer");
+    ORN_REQUIRE(B > 0 && Ch > 0 && H > 0 && W > 0, "loss_fwd_bwd: bad sizes");
+    if (ws_bytes < orn_loss_ws_bytes(B, Ch, H, W)) {
+        orn_set_error("loss_fwd_bwd: workspace %zu < %zu", ws_bytes, orn_loss_ws_bytes(B, Ch, H, W));
+        return ORN_E_WS;
+    }
+    return orn_launch_loss(pred, target, nullptr, 0, B, Ch, H, W, loss_type, loss_scale, stats, dpred, (float *)ws,
+                           (hipStream_t)stream);
+}

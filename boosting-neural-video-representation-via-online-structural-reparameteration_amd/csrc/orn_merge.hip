@@ -1,0 +1,235 @@
+// A3  ERB online re-parameterisation (model.py:450-516) and its backward.
+//
+// Both the forward and the backward are chains of small fp32 contractions over weight-shaped
+// operands (a few MB, L2/MALL resident).  They run on one generic strided/batched fp32 GEMM whose
+// every output element is a SINGLE k-ordered fmaf chain starting from +0.0f -- the summation order
+// oracle/merge_ref.c specifies -- so the forward is bit-exact against the CPU oracle.
+#include "orn_common.h"
+
+struct GemmP {
+    const float *A, *B;
+    float *C;
+    int M, N, K;
+    long sam, sak;   // A(m,k) = A[m*sam + k*sak]
+    long sbk, sbn;   // B(k,n) = B[k*sbk + n*sbn]
+    long scm, scn;   // C(m,n) = C[m*scm + n*scn]
+    long ba, bb, bc; // per-batch element offsets (blockIdx.z)
+    int a_kfast, b_nfast;
+    // epilogue 1 (merge combine): C = (w3x3 + (P(w1x3) + P(w3x1))) + acc, n = c*9 + ij
+    int epi;
+    const float *w3x3, *w1x3, *w3x1;
+    int Cch;
+};
+
+#define GT 64
+#define GK 16
+#define GLD (GT + 4)
+
+__global__ void __launch_bounds__(256) k_gemm_f32(GemmP p)
+{
+    __shared__ __attribute__((aligned(16))) float As[GK][GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[GK][GLD];
+    const int t = threadIdx.x;
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const float *A = p.A + (long)blockIdx.z * p.ba;
+    const float *B = p.B + (long)blockIdx.z * p.bb;
+    float *C = p.C + (long)blockIdx.z * p.bc;
+    const int tx = t & 15, ty = t >> 4;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+    for (int k0 = 0; k0 < p.K; k0 += GK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int kk, m;
+            if (p.a_kfast) { kk = t & 15; m = (t >> 4) + 16 * i; }
+            else           { m = t & 63;  kk = (t >> 6) + 4 * i; }
+            const int gm = m0 + m, gk = k0 + kk;
+            As[kk][m] = (gm < p.M && gk < p.K) ? A[(long)gm * p.sam + (long)gk * p.sak] : 0.f;
+            int kb, n;
+            if (p.b_nfast) { n = t & 63;  kb = (t >> 6) + 4 * i; }
+            else           { kb = t & 15; n = (t >> 4) + 16 * i; }
+            const int gn = n0 + n, gkb = k0 + kb;
+            Bs[kb][n] = (gn < p.N && gkb < p.K) ? B[(long)gkb * p.sbk + (long)gn * p.sbn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GK; ++kk) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(&As[kk][ty * 4]);
+            const float4 b4 = *reinterpret_cast<const float4 *>(&Bs[kk][tx * 4]);
+            const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+            const float b[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gm = m0 + ty * 4 + i;
+        if (gm >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gn = n0 + tx * 4 + j;
+            if (gn >= p.N) continue;
+            float r = acc[i][j];
+            if (p.epi == 1) {
+                const int c = gn / 9, ij = gn % 9, ii = ij / 3, jj = ij % 3;
+                const long oc = (long)gm * p.Cch + c;
+                const float p13 = (ii == 1) ? p.w1x3[oc * 3 + jj] : 0.f;
+                const float p31 = (jj == 1) ? p.w3x1[oc * 3 + ii] : 0.f;
+                r = (p.w3x3[(long)gm * p.N + gn] + (p13 + p31)) + r;   // association of model.py:475,495
+            }
+            C[(long)gm * p.scm + (long)gn * p.scn] = r;
+        }
+    }
+}
+
+static int launch_gemm(GemmP p, int batch, hipStream_t st, const char *name)
+{
+    p.a_kfast = (labs(p.sak) <= labs(p.sam)) ? 1 : 0;
+    p.b_nfast = (labs(p.sbn) <= labs(p.sbk)) ? 1 : 0;
+    hipLaunchKernelGGL(k_gemm_f32, dim3(orn_cdiv(p.N, GT), orn_cdiv(p.M, GT), batch), dim3(256), 0, st, p);
+    ORN_LAUNCH_CHECK(name);
+    return 0;
+}
+
+__global__ void k_bias3(const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ c, int n,
+                        float *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + (b[i] + c[i]);     // b3x3 + (b1x3 + b3x1), model.py:476,496
+}
+
+int orn_launch_merge_fwd(const float *w3x3, const float *b3x3, const float *w3x1, const float *b3x1,
+                         const float *w1x3, const float *b1x3, const float *w1, const float *w2, const float *w3,
+                         int C, int O, float *T, float *wf, float *bf, hipStream_t st)
+{
+    const int K2 = 2 * C;
+    GemmP p = {};
+    // T[m,c,ij] = sum_k W2[m,k,ij] * W1[k,c]     (9 batches over ij)
+    p.A = w2; p.B = w1; p.C = T;
+    p.M = O; p.N = C; p.K = K2;
+    p.sam = (long)K2 * 9; p.sak = 9; p.sbk = C; p.sbn = 1; p.scm = (long)C * 9; p.scn = 9;
+    p.ba = 1; p.bb = 0; p.bc = 1; p.epi = 0;
+    ORN_TRY(launch_gemm(p, 9, st, "merge_T"));
+    // Wf[o,e] = (W3x3 + (P13 + P31))[o,e] + sum_m W3[o,m] * T[m,e]
+    GemmP q = {};
+    q.A = w3; q.B = T; q.C = wf;
+    q.M = O; q.N = C * 9; q.K = O;
+    q.sam = O; q.sak = 1; q.sbk = (long)C * 9; q.sbn = 1; q.scm = (long)C * 9; q.scn = 1;
+    q.epi = 1; q.w3x3 = w3x3; q.w1x3 = w1x3; q.w3x1 = w3x1; q.Cch = C;
+    ORN_TRY(launch_gemm(q, 1, st, "merge_S"));
+    hipLaunchKernelGGL(k_bias3, dim3(orn_cdiv(O, 256)), dim3(256), 0, st, b3x3, b1x3, b3x1, O, bf);
+    ORN_LAUNCH_CHECK("merge_bias");
+    return 0;
+}
+
+extern "C" int orn_erb_merge_fwd(const float *w3x3, const float *b3x3, const float *w3x1, const float *b3x1,
+                                 const float *w1x3, const float *b1x3, const float *w1, const float *w2,
+                                 const float *w3, int C, int O, float *T, float *wf, float *bf, void *stream)
+{
+    ORN_REQUIRE(w3x3 && b3x3 && w3x1 && b3x1 && w1x3 && b1x3 && w1 && w2 && w3 && T && wf && bf, "erb_merge_fwd: null pointer");
+    ORN_REQUIRE(C > 0 && O > 0, "erb_merge_fwd: bad sizes C=%d O=%d", C, O);
+    return orn_launch_merge_fwd(w3x3, b3x3, w3x1, b3x1, w1x3, b1x3, w1, w2, w3, C, O, T, wf, bf, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward (closed forms of SURVEY 8a row A3)
+// ------------------------------------------------------------------------------------------------
+// d1x3[o,c,0,j] = G[o,c,1,j];  d3x1[o,c,i,0] = G[o,c,i,1];  optional copy d3x3 = G; bias fan-out
+__global__ void k_merge_bwd_slices(const float *__restrict__ g, const float *__restrict__ dbf, long OC, int O,
+                                   float *__restrict__ d3x3, float *__restrict__ db3x3, float *__restrict__ d3x1,
+                                   float *__restrict__ db3x1, float *__restrict__ d1x3, float *__restrict__ db1x3)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < OC) {
+        const float *gg = g + i * 9;
+        float v[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[k] = gg[k];
+        if (d3x3 != g) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) d3x3[i * 9 + k] = v[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            d1x3[i * 3 + k] = v[3 + k];
+            d3x1[i * 3 + k] = v[3 * k + 1];
+        }
+    }
+    if (i < O) {
+        const float d = dbf[i];
+        if (db3x3 != dbf) db3x3[i] = d;
+        db3x1[i] = d;
+        db1x3[i] = d;
+    }
+}
+
+extern "C" size_t orn_erb_merge_bwd_ws_bytes(int C, int O)
+{
+    // dT [O*C*9] + dW1 partials [9][2C*C]
+    return orn_align(((size_t)O * C * 9 + 9 * (size_t)2 * C * C) * sizeof(float));
+}
+
+int orn_launch_merge_bwd(const float *g, const float *dbf, const float *w1, const float *w2, const float *w3,
+                         const float *T, int C, int O, float *d3x3, float *db3x3, float *d3x1, float *db3x1,
+                         float *d1x3, float *db1x3, float *dw1, float *dw2, float *dw3, float *ws, hipStream_t st)
+{
+    const int K2 = 2 * C;
+    const long n = (long)C * 9;
+    float *dT = ws;
+    float *dw1p = ws + (size_t)O * n;
+    hipLaunchKernelGGL(k_merge_bwd_slices, dim3(orn_cdiv((long)O * C, 256)), dim3(256), 0, st, g, dbf, (long)O * C, O,
+                       d3x3, db3x3, d3x1, db3x1, d1x3, db1x3);
+    ORN_LAUNCH_CHECK("merge_bwd_slices");
+    {   // dW3[o,m] = sum_e G[o,e] * T[m,e]
+        GemmP p = {};
+        p.A = g; p.B = T; p.C = dw3; p.M = O; p.N = O; p.K = (int)n;
+        p.sam = n; p.sak = 1; p.sbk = 1; p.sbn = n; p.scm = O; p.scn = 1;
+        ORN_TRY(launch_gemm(p, 1, st, "merge_dW3"));
+    }
+    {   // dT[m,e] = sum_o W3[o,m] * G[o,e]
+        GemmP p = {};
+        p.A = w3; p.B = g; p.C = dT; p.M = O; p.N = (int)n; p.K = O;
+        p.sam = 1; p.sak = O; p.sbk = n; p.sbn = 1; p.scm = n; p.scn = 1;
+        ORN_TRY(launch_gemm(p, 1, st, "merge_dT"));
+    }
+    {   // dW2[m,k,ij] = sum_c dT[m,c,ij] * W1[k,c]        (9 batches)
+        GemmP p = {};
+        p.A = dT; p.B = w1; p.C = dw2; p.M = O; p.N = K2; p.K = C;
+        p.sam = n; p.sak = 9; p.sbk = 1; p.sbn = C; p.scm = (long)K2 * 9; p.scn = 9;
+        p.ba = 1; p.bb = 0; p.bc = 1;
+        ORN_TRY(launch_gemm(p, 9, st, "merge_dW2"));
+    }
+    {   // dW1[k,c] = sum_ij sum_m W2[m,k,ij] * dT[m,c,ij]  (9 batched partials, then fixed-order sum)
+        GemmP p = {};
+        p.A = w2; p.B = dT; p.C = dw1p; p.M = K2; p.N = C; p.K = O;
+        p.sam = 9; p.sak = (long)K2 * 9; p.sbk = n; p.sbn = 9; p.scm = C; p.scn = 1;
+        p.ba = 1; p.bb = 1; p.bc = (long)K2 * C;
+        ORN_TRY(launch_gemm(p, 9, st, "merge_dW1"));
+        ORN_TRY(orn_launch_reduce_rows(dw1p, 9, (size_t)K2 * C, (size_t)K2 * C, dw1, st));
+    }
+    return 0;
+}
+
+extern "C" int orn_erb_merge_bwd(const float *g, const float *dbf, const float *w1, const float *w2, const float *w3,
+                                 const float *T, int C, int O, float *d3x3, float *db3x3, float *d3x1, float *db3x1,
+                                 float *d1x3, float *db1x3, float *dw1, float *dw2, float *dw3, void *ws,
+                                 size_t ws_bytes, void *stream)
+{
+    ORN_REQUIRE(g && dbf && w1 && w2 && w3 && T && d3x3 && db3x3 && d3x1 && db3x1 && d1x3 && db1x3 && dw1 && dw2 && dw3 && ws,
+                "erb_merge_bwd: null pointer");
+    ORN_REQUIRE(C > 0 && O > 0, "erb_merge_bwd: bad sizes");
+    if (ws_bytes < orn_erb_merge_bwd_ws_bytes(C, O)) {
+        orn_set_error("erb_merge_bwd: workspace %zu < %zu", ws_bytes, orn_erb_merge_bwd_ws_bytes(C, O));
+        return ORN_E_WS;
+    }
+    return orn_launch_merge_bwd(g, dbf, w1, w2, w3, T, C, O, d3x3, db3x3, d3x1, db3x1, d1x3, db1x3, dw1, dw2, dw3,
+                                (float *)ws, (hipStream_t)stream);
+}

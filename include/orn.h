@@ -1,0 +1,165 @@
+/* orn.h -- C ABI of liborn.so: the MI355X-native (gfx950) Online-RepNeRV training hot path.
+ *
+ * The reference (maoqingyu1996/Boosting-Neural-Video-Representation-via-Online-Structural-
+ * Reparameteration) is pure Python and exposes no FFI; the interface it *does* expose for this path is
+ * the Python surface of model.py / utils.py / main_train.py.  Each entry point below names the
+ * reference call site it replaces (file:line, relative to the reference root).  The Python mirror
+ * in boosting-..._amd/ binds these with ctypes (see INTEGRATION.md for the stub a reference
+ * maintainer would add).
+ *
+ * Conventions
+ *   - Every tensor argument is a raw DEVICE pointer (torch.Tensor.data_ptr()).  fp32, NCHW,
+ *     contiguous, weights [O,C,kh,kw] exactly as PyTorch stores them.  The caller allocates every
+ *     input, output and workspace and keeps them alive until the stream has drained.  No ownership
+ *     is transferred; the library allocates no device memory.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     all work is enqueued there, nothing synchronises, every call is hipGraph-capturable.
+ *   - Return value: 0 = success; < 0 = argument / shape error (text via orn_last_error);
+ *     > 0 = hipError_t of a failed launch.  Nothing throws across the ABI, nothing calls exit().
+ *   - All reductions are fixed-order two-pass trees: results are run-to-run bit-identical.
+ *   - `ws` arguments are scratch; the required size comes from the matching *_ws_bytes().
+ */
+#ifndef ORN_H_
+#define ORN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORN_VERSION 100          /* 0.1.0 */
+#define ORN_MAX_LAYERS 8
+
+#define ORN_OK 0
+#define ORN_E_ARG (-1)           /* bad pointer / size / unsupported shape */
+#define ORN_E_WS (-2)            /* workspace too small */
+#define ORN_E_STATE (-3)         /* engine used in the wrong state */
+
+int orn_version(void);
+/* Copies the last error text of the calling thread into buf (NUL-terminated); returns its length. */
+int orn_last_error(char *buf, size_t n);
+
+/* ---- A1  PositionalEncoding.forward                                   utils.py:121-129 ------
+ * out[b, 2i] = sin(arg), out[b, 2i+1] = cos(arg), arg = fp32(fp32(pos[b]*fp32(lbase^i))*fp32(pi)).
+ * lbase_pow[i] = (float)(lbase**i) is computed by the caller in double (Python `lbase ** i`). */
+int orn_pe_fwd(const float *pos, int B, const float *lbase_pow, int levels, float *out, void *stream);
+
+/* ---- A2  MLP stem (Linear+SiLU, Linear+SiLU)                         model.py:174-188,612 ----
+ * pre1/h1: [B,Hd], pre2/h2: [B,Nout] (h2 is the block input viewed [B,C,fc_h,fc_w]). */
+int orn_stem_fwd(const float *embed, const float *w0, const float *b0, const float *w1, const float *b1,
+                 int B, int E, int Hd, int Nout, float *pre1, float *h1, float *pre2, float *h2,
+                 void *stream);
+/* dh2 [B,Nout] -> dw0,db0,dw1,db1 (overwritten).  ws: B*(Hd+Nout) floats. */
+int orn_stem_bwd(const float *embed, const float *w1, const float *pre1, const float *h1, const float *pre2,
+                 const float *dh2, int B, int E, int Hd, int Nout, float *dw0, float *db0, float *dw1,
+                 float *db1, float *ws, void *stream);
+
+/* ---- A3  NeRVBlock.get_equivalent_kernel_bias (online ERB merge)     model.py:450-516 --------
+ * T[O,C,3,3] (kept for the backward), wf[O,C,3,3], bf[O].  Bit-exact against oracle/merge_ref.c:
+ * both contractions are single k-ordered fmaf chains. */
+int orn_erb_merge_fwd(const float *w3x3, const float *b3x3, const float *w3x1, const float *b3x1,
+                      const float *w1x3, const float *b1x3, const float *w1, const float *w2,
+                      const float *w3, int C, int O, float *T, float *wf, float *bf, void *stream);
+size_t orn_erb_merge_bwd_ws_bytes(int C, int O);
+/* g = dL/dwf [O,C,3,3], dbf = dL/dbf [O] -> gradients of the 9 branch tensors (overwritten). */
+int orn_erb_merge_bwd(const float *g, const float *dbf, const float *w1, const float *w2, const float *w3,
+                      const float *T, int C, int O, float *d3x3, float *db3x3, float *d3x1, float *db3x1,
+                      float *d1x3, float *db1x3, float *dw1, float *dw2, float *dw3, void *ws,
+                      size_t ws_bytes, void *stream);
+
+/* ---- A4  NeRVBlock.forward: conv3x3(pad 1)+bias -> PixelShuffle(s) -> SiLU   model.py:539,567 --
+ * x [B,C,H,W]; wf [O,C,3,3]; bf [O]; O = Cn*s*s.  z (pre-activation, post-shuffle) and
+ * a = SiLU(z): [B,Cn,H*s,W*s].  z may be NULL for inference (decode). */
+int orn_conv3x3_ps_silu_fwd(const float *x, const float *wf, const float *bf, int B, int C, int O, int H,
+                            int W, int s, float *z, float *a, void *stream);
+size_t orn_conv3x3_ps_silu_bwd_ws_bytes(int B, int C, int O, int H, int W);
+/* da [B,Cn,Hs,Ws] -> dx [B,C,H,W] (NULL to skip), dwf [O,C,3,3], dbf [O] (overwritten). */
+int orn_conv3x3_ps_silu_bwd(const float *x, const float *wf, const float *z, const float *da, int B, int C,
+                            int O, int H, int W, int s, float *dx, float *dwf, float *dbf, void *ws,
+                            size_t ws_bytes, void *stream);
+
+/* ---- A5  head: 1x1 conv -> (tanh+1)/2 or sigmoid                      model.py:621-622 --------
+ * a [B,C,H,W]; w [3,C,1,1]; b [3]; out [B,3,H,W]. */
+int orn_head_fwd(const float *a, const float *w, const float *b, int B, int C, int H, int W, int sigmoid,
+                 float *out, void *stream);
+size_t orn_head_bwd_ws_bytes(int B, int C, int H, int W);
+int orn_head_bwd(const float *a, const float *w, const float *out, const float *dout, int B, int C, int H,
+                 int W, int sigmoid, float *da, float *dw, float *db, void *ws, size_t ws_bytes,
+                 void *stream);
+
+/* ---- A7 + A10  loss_fn (L2 | L1 | Fusion6) and psnr_fn               utils.py:139-199 ---------
+ * pred/target [B,Ch,H,W].  stats (device, 8 floats):
+ *   [0] loss  [1] mean|p-t|  [2] mean (p-t)^2  [3] ssim (0 unless Fusion6)  [4] psnr = -10 log10(mse)
+ * dpred = dLoss/dpred * loss_scale (NULL: forward only). */
+#define ORN_LOSS_L2 0
+#define ORN_LOSS_L1 1
+#define ORN_LOSS_FUSION6 2
+size_t orn_loss_ws_bytes(int B, int Ch, int H, int W);
+int orn_loss_fwd_bwd(const float *pred, const float *target, int B, int Ch, int H, int W, int loss_type,
+                     float loss_scale, float *stats, float *dpred, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- A9  optim.Adam.step over one flat arena                          main_train.py:196,250 ---
+ * p,g,m,v: n floats each.  step = 1-based global step.  weight decay 0, amsgrad off. */
+int orn_adam_step(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1,
+                  float beta2, float eps, int step, void *stream);
+
+/* ---- A11  the whole per-frame training step as one engine           main_train.py:229-254 ----
+ * The engine owns no memory: the caller passes four parameter-shaped arenas (params, grads, adam m,
+ * adam v) laid out by `param_off` and one workspace.  Tensors inside an arena keep the PyTorch
+ * shapes, so state_dict tensors can be views of `params`. */
+typedef struct orn_layer_desc {
+    int32_t C, O, s, H, W;          /* conv in-ch, conv out-ch (= Cn*s*s), stride, input H, W */
+    /* offsets in floats into the parameter arenas; -1 = tensor absent */
+    int64_t w3x3, b3x3;             /* ERB 3x3 branch, or the single conv of vanilla / deploy */
+    int64_t w3x1, b3x1, w1x3, b1x3; /* ERB only */
+    int64_t w1, w2, w3;             /* ERB only: 1x1 -> 3x3 -> 1x1 */
+} orn_layer_desc;
+
+typedef struct orn_engine_desc {
+    int32_t n_layers;
+    int32_t erb;                    /* 1: ERB online merge; 0: single 3x3 conv per block */
+    int32_t embed_len, stem_dim, fc_h, fc_w, fc_dim;
+    int32_t sigmoid;                /* head activation (model.py:622) */
+    int32_t loss_type;              /* ORN_LOSS_* */
+    int32_t precision;              /* 0: fp32 everywhere; 1: bf16 activations / bf16 MFMA convs */
+    float beta1, beta2, eps;
+    int64_t stem_w0, stem_b0, stem_w1, stem_b1, head_w, head_b;
+    int64_t n_params;               /* arena length in floats */
+    orn_layer_desc layer[ORN_MAX_LAYERS];
+} orn_engine_desc;
+
+/* One entry of the per-step schedule (device array, uploaded per epoch by the caller). */
+typedef struct orn_step_sched {
+    int32_t frame;                  /* index into frames / embed table */
+    int32_t step;                   /* 1-based global optimiser step (Adam bias correction) */
+    float lr;                       /* adjust_lr() value for this step (utils.py:240-259) */
+    float pad;
+} orn_step_sched;
+
+typedef struct orn_engine orn_engine;
+
+size_t orn_engine_ws_bytes(const orn_engine_desc *d);
+int orn_engine_create(const orn_engine_desc *d, float *params, float *grads, float *adam_m, float *adam_v,
+                      void *ws, size_t ws_bytes, orn_engine **out);
+void orn_engine_destroy(orn_engine *e);
+/* Forward only (decode): embed [E] device -> img [3,H,W] device. */
+int orn_engine_decode(orn_engine *e, const float *embed, float *img, void *stream);
+/* One optimiser step.  frames [n_frames,3,H,W], embeds [n_frames,E] (device); sched: device array,
+ * `cursor` a device int32 the step reads and post-increments, so `n` back-to-back steps consume
+ * sched[cursor..cursor+n).  stats_out: device [n_slots][8] ring written at slot (cursor % n_slots). */
+int orn_engine_train_step(orn_engine *e, const float *frames, const float *embeds,
+                          const orn_step_sched *sched, int32_t *cursor, float *stats_out, int32_t n_slots,
+                          void *stream);
+/* Capture one train step into a hipGraph on `stream` and replay it n times (same arguments as above). */
+int orn_engine_train_steps_graph(orn_engine *e, const float *frames, const float *embeds,
+                                 const orn_step_sched *sched, int32_t *cursor, float *stats_out,
+                                 int32_t n_slots, int32_t n_steps, void *stream);
+/* Merged (deploy) kernel/bias of layer i, valid after a decode / train step (model.py:395-448). */
+int orn_engine_fused_kernel(orn_engine *e, int layer, const float **wf, const float **bf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORN_H_ */
