@@ -1,7 +1,7 @@
 """ctypes binding of liborn.so (include/orn.h).  Fails loudly when the library is missing."""
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORN_MAX_LAYERS = 8
@@ -26,7 +26,7 @@ class EngineDesc(ctypes.Structure):
     _fields_ = [('n_layers', c_int32), ('erb', c_int32), ('embed_len', c_int32), ('stem_dim', c_int32),
                 ('fc_h', c_int32), ('fc_w', c_int32), ('fc_dim', c_int32), ('sigmoid', c_int32),
                 ('loss_type', c_int32), ('precision', c_int32),
-                ('beta1', c_float), ('beta2', c_float), ('eps', c_float),
+                ('beta1', c_double), ('beta2', c_double), ('eps', c_double),
                 ('stem_w0', c_int64), ('stem_b0', c_int64), ('stem_w1', c_int64), ('stem_b1', c_int64),
                 ('head_w', c_int64), ('head_b', c_int64), ('n_params', c_int64),
                 ('layer', LayerDesc * ORN_MAX_LAYERS)]
@@ -50,7 +50,7 @@ _SIGS = {
     'orn_head_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
     'orn_loss_ws_bytes': (c_size_t, [c_int] * 4),
     'orn_loss_fwd_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, P, P, P, c_size_t, P]),
-    'orn_adam_step': (c_int, [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_int, P]),
+    'orn_adam_step': (c_int, [P, P, P, P, c_size_t, c_double, c_double, c_double, c_double, c_int, P]),
     'orn_engine_ws_bytes': (c_size_t, [POINTER(EngineDesc)]),
     'orn_engine_create': (c_int, [POINTER(EngineDesc), P, P, P, P, P, c_size_t, POINTER(c_void_p)]),
     'orn_engine_destroy': (None, [P]),

@@ -78,6 +78,16 @@ __device__ __forceinline__ float orn_block_sum(float v, float *smem /* >= 16 flo
     return r;
 }
 
+// Device-side state of the step in flight (engine): schedule entry + derived Adam scalars.
+struct OrnStepCur {
+    int32_t frame, step;
+    float lr;
+    float step_size;   // lr / (1 - beta1^step), formed in double
+    float sqrt_bc2;    // sqrt(1 - beta2^step), formed in double
+    int32_t slot;
+    int32_t pad[2];
+};
+
 // ---- internal cross-file entry points (not exported) -----------------------------------------
 // Generic deterministic column reduce: out[j] = sum_{i<rows} in[i*ld + j], fixed order.
 int orn_launch_reduce_rows(const float *in, int rows, size_t ld, size_t n, float *out, hipStream_t st);

@@ -388,18 +388,15 @@ extern "C" int orn_head_bwd(const float *a, const float *w, const float *out, co
 // ------------------------------------------------------------------------------------------------
 // A9  Adam                                                                 main_train.py:196,250
 // ------------------------------------------------------------------------------------------------
-// hyper (device or by value): lr, step.  Matches torch.optim.Adam's algebra:
+// Matches torch.optim.Adam's algebra:
 //   m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// step_size / sqrt_bc2 come by value (per-op API) or from the engine's device-side step state.
 __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
-                       size_t n, float lr_v, int step_v, const orn_step_sched *__restrict__ sp, float beta1, float beta2,
-                       float eps, float inv_gscale)
+                       size_t n, float step_size_v, float sqrt_bc2_v, const OrnStepCur *__restrict__ sp, float beta1,
+                       float omb1, float beta2, float omb2, float eps, float inv_gscale)
 {
-    float lr = lr_v;
-    int step = step_v;
-    if (sp) { lr = sp->lr; step = sp->step; }
-    const float bc1 = 1.0f - powf(beta1, (float)step);
-    const float bc2 = 1.0f - powf(beta2, (float)step);
-    const float step_size = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+    float step_size = step_size_v, sqrt_bc2 = sqrt_bc2_v;
+    if (sp) { step_size = sp->step_size; sqrt_bc2 = sp->sqrt_bc2; }
     const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i0 >= n) return;
     if (i0 + 4 <= n) {
@@ -412,9 +409,9 @@ __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float gg = gp[k] * inv_gscale;
-            mp[k] = beta1 * mp[k] + (1.0f - beta1) * gg;
-            vp[k] = beta2 * vp[k] + (1.0f - beta2) * gg * gg;
-            pp[k] -= step_size * (mp[k] / (sqrtf(vp[k]) * inv_sqrt_bc2 + eps));
+            mp[k] = __fadd_rn(__fmul_rn(beta1, mp[k]), __fmul_rn(omb1, gg));
+            vp[k] = __fadd_rn(__fmul_rn(beta2, vp[k]), __fmul_rn(__fmul_rn(omb2, gg), gg));
+            pp[k] -= step_size * (mp[k] / (sqrtf(vp[k]) / sqrt_bc2 + eps));
         }
         *reinterpret_cast<float4 *>(p + i0) = pv;
         *reinterpret_cast<float4 *>(m + i0) = mv;
@@ -422,26 +419,28 @@ __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float
     } else {
         for (size_t i = i0; i < n; ++i) {
             const float gg = g[i] * inv_gscale;
-            const float mm = beta1 * m[i] + (1.0f - beta1) * gg;
-            const float vv = beta2 * v[i] + (1.0f - beta2) * gg * gg;
+            const float mm = __fadd_rn(__fmul_rn(beta1, m[i]), __fmul_rn(omb1, gg));
+            const float vv = __fadd_rn(__fmul_rn(beta2, v[i]), __fmul_rn(__fmul_rn(omb2, gg), gg));
             m[i] = mm;
             v[i] = vv;
-            p[i] -= step_size * (mm / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+            p[i] -= step_size * (mm / (sqrtf(vv) / sqrt_bc2 + eps));
         }
     }
 }
 
-int orn_launch_adam(float *p, const float *g, float *m, float *v, size_t n, float lr, int step,
-                    const orn_step_sched *sp, float beta1, float beta2, float eps, float inv_gscale, hipStream_t st)
+int orn_launch_adam(float *p, const float *g, float *m, float *v, size_t n, double lr, int step, const OrnStepCur *sp,
+                    double beta1, double beta2, double eps, float inv_gscale, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_adam, dim3(orn_cdiv((long)orn_cdiv((long)n, 4), 256)), dim3(256), 0, st, p, g, m, v, n, lr, step,
-                       sp, beta1, beta2, eps, inv_gscale);
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(k_adam, dim3(orn_cdiv((long)orn_cdiv((long)n, 4), 256)), dim3(256), 0, st, p, g, m, v, n,
+                       (float)(lr / bc1), (float)sqrt(bc2), sp, (float)beta1, (float)(1.0 - beta1), (float)beta2,
+                       (float)(1.0 - beta2), (float)eps, inv_gscale);
     ORN_LAUNCH_CHECK("adam");
     return 0;
 }
 
-extern "C" int orn_adam_step(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1,
-                             float beta2, float eps, int step, void *stream)
+extern "C" int orn_adam_step(float *p, const float *g, float *m, float *v, size_t n, double lr, double beta1,
+                             double beta2, double eps, int step, void *stream)
 {
     ORN_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
     ORN_REQUIRE(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, "adam_step: arenas must be 16-byte aligned");

@@ -21,8 +21,7 @@ struct orn_engine {
     float *img, *dimg, *stats;
     float *loss_ws;
     float *scratch;                  // shared scratch for the backward kernels
-    orn_step_sched *cur;             // current step's schedule entry (device)
-    int32_t *cur_slot;               // ring slot of the current step (device)
+    OrnStepCur *cur;                 // state of the step in flight (device)
     LayerBuf L[ORN_MAX_LAYERS];
     int Hout, Wout, Cn_last;
     // graph cache (one captured train step)
@@ -91,11 +90,11 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
     const size_t s3 = orn_head_bwd_ws_bytes(1, Cn, H, W) / 4;
     if (s3 > scratch) scratch = s3;
     float *scr = take(scratch);
-    float *cur = take(8);
+    float *cur = take(16);
     if (e) {
         e->pre1 = pre1; e->h1 = h1; e->pre2 = pre2; e->h2 = h2; e->dh2 = dh2;
         e->img = img; e->dimg = dimg; e->stats = stats; e->loss_ws = loss_ws; e->scratch = scr;
-        e->cur = (orn_step_sched *)cur; e->cur_slot = (int32_t *)(cur + 4);
+        e->cur = (OrnStepCur *)cur;
         for (int i = 0; i < d->n_layers; ++i) e->L[i] = L[i];
         e->Hout = H; e->Wout = W; e->Cn_last = Cn;
     }
@@ -155,19 +154,25 @@ extern "C" int orn_engine_fused_kernel(orn_engine *e, int layer, const float **w
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void k_advance(const orn_step_sched *__restrict__ sched, int32_t *cursor, int32_t n_slots,
-                          orn_step_sched *cur, int32_t *cur_slot)
+__global__ void k_advance(const orn_step_sched *__restrict__ sched, int32_t *cursor, int32_t n_slots, double beta1,
+                          double beta2, OrnStepCur *cur)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const int32_t c = *cursor;
-        *cur = sched[c];
-        *cur_slot = n_slots > 0 ? c % n_slots : 0;
+        const orn_step_sched s = sched[c];
+        cur->frame = s.frame;
+        cur->step = s.step;
+        cur->lr = s.lr;
+        // torch.optim.Adam: bias corrections in double, rounded to fp32 once
+        const double bc1 = 1.0 - pow(beta1, (double)s.step), bc2 = 1.0 - pow(beta2, (double)s.step);
+        cur->step_size = (float)((double)s.lr / bc1);
+        cur->sqrt_bc2 = (float)sqrt(bc2);
+        cur->slot = n_slots > 0 ? c % n_slots : 0;
         *cursor = c + 1;
     }
 }
 
-__global__ void k_publish_stats(const float *__restrict__ stats, const orn_step_sched *cur, const int32_t *cur_slot,
-                                float *ring)
+__global__ void k_publish_stats(const float *__restrict__ stats, const OrnStepCur *cur, float *ring)
 {
     const int t = threadIdx.x;
     if (t < 8) {
@@ -175,7 +180,7 @@ __global__ void k_publish_stats(const float *__restrict__ stats, const orn_step_
         if (t == 5) v = cur->lr;
         if (t == 6) v = (float)cur->frame;
         if (t == 7) v = (float)cur->step;
-        ring[(size_t)(*cur_slot) * 8 + t] = v;
+        ring[(size_t)cur->slot * 8 + t] = v;
     }
 }
 
@@ -218,14 +223,14 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
     float *P = e->params, *G = e->grads;
     const int Nout = d.fc_h * d.fc_w * d.fc_dim;
     const size_t HWo = (size_t)e->Hout * e->Wout;
-    hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, sched, cursor, n_slots, e->cur, e->cur_slot);
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, sched, cursor, n_slots, d.beta1, d.beta2, e->cur);
     ORN_LAUNCH_CHECK("advance");
     const int *fidx = &e->cur->frame;
     ORN_TRY(forward(e, embeds, fidx, true, st));
     ORN_TRY(orn_launch_loss(e->img, frames, fidx, 3 * HWo, 1, 3, e->Hout, e->Wout, d.loss_type, 1.0f, e->stats, e->dimg,
                             e->loss_ws, st));
     if (stats_out) {
-        hipLaunchKernelGGL(k_publish_stats, dim3(1), dim3(64), 0, st, e->stats, e->cur, e->cur_slot, stats_out);
+        hipLaunchKernelGGL(k_publish_stats, dim3(1), dim3(64), 0, st, e->stats, e->cur, stats_out);
         ORN_LAUNCH_CHECK("publish_stats");
     }
     const int nl = d.n_layers;
@@ -245,7 +250,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
     }
     ORN_TRY(orn_launch_stem_bwd(embeds, fidx, d.embed_len, P + d.stem_w1, e->pre1, e->h1, e->pre2, e->dh2, 1, d.embed_len,
                                 d.stem_dim, Nout, G + d.stem_w0, G + d.stem_b0, G + d.stem_w1, G + d.stem_b1, e->scratch, st));
-    ORN_TRY(orn_launch_adam(P, G, e->m, e->v, (size_t)d.n_params, 0.f, 1, e->cur, d.beta1, d.beta2, d.eps, 1.0f, st));
+    ORN_TRY(orn_launch_adam(P, G, e->m, e->v, (size_t)d.n_params, 0.0, 1, e->cur, d.beta1, d.beta2, d.eps, 1.0f, st));
     return 0;
 }
 

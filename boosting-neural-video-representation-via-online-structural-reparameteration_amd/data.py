@@ -1,0 +1,24 @@
+"""Synthetic video resident in HBM (there is no dataset access): the frame-ingest side of the hot
+path (CustomDataSet, model.py:11-70) is replaced by frames generated on the device."""
+import math
+
+import torch
+
+
+def synthetic_video(frames: int, h: int, w: int, seed: int = 1234, device='cuda') -> torch.Tensor:
+    """[frames,3,h,w] fp32 in [0,1]: V[k] = clip(0.5 + sum_4 (0.25/4) sin(2pi(fx x + fy y + k/frames + ph))
+    + 0.1 U(-1,1)) with 4 random (fx, fy, ph) per channel (SURVEY 8d recipe).  Deterministic per seed."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    ys = torch.linspace(0, 1, h, device=device).view(1, 1, h, 1)
+    xs = torch.linspace(0, 1, w, device=device).view(1, 1, 1, w)
+    ks = (torch.arange(frames, dtype=torch.float32, device=device) / frames).view(frames, 1, 1, 1)
+    v = torch.full((frames, 3, h, w), 0.5, device=device)
+    for _ in range(4):
+        fx = (torch.rand(3, generator=g) * 6 + 0.5).view(1, 3, 1, 1).to(device)
+        fy = (torch.rand(3, generator=g) * 6 + 0.5).view(1, 3, 1, 1).to(device)
+        ph = torch.rand(3, generator=g).view(1, 3, 1, 1).to(device)
+        v += (0.25 / 4) * torch.sin(2 * math.pi * (fx * xs + fy * ys + ks + ph))
+    gd = torch.Generator(device=device).manual_seed(seed)
+    noise = torch.rand((frames, 3, h, w), generator=gd, device=device)
+    v += 0.1 * (noise * 2 - 1)
+    return v.clamp_(0, 1).contiguous()

@@ -5,7 +5,7 @@ current torch stream and returns torch tensors.  Nothing falls back to PyTorch m
 or a missing library raises OrnError.
 """
 import math
-from ctypes import c_float, c_int, c_size_t
+from ctypes import c_double, c_float, c_int, c_size_t
 
 import torch
 
@@ -221,5 +221,5 @@ def adam_step_(p, g, m, v, lr: float, step: int, beta1: float = 0.5, beta2: floa
         if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
             raise _lib.OrnError('adam_step_: arenas must be contiguous CUDA fp32 tensors')
     n = p.numel()
-    check(lib().orn_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), c_size_t(n), c_float(lr), c_float(beta1), c_float(beta2),
-                              c_float(eps), c_int(step), stream()), 'orn_adam_step')
+    check(lib().orn_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), c_size_t(n), c_double(lr), c_double(beta1), c_double(beta2),
+                              c_double(eps), c_int(step), stream()), 'orn_adam_step')

@@ -101,9 +101,11 @@ int orn_loss_fwd_bwd(const float *pred, const float *target, int B, int Ch, int 
                      float loss_scale, float *stats, float *dpred, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- A9  optim.Adam.step over one flat arena                          main_train.py:196,250 ---
- * p,g,m,v: n floats each.  step = 1-based global step.  weight decay 0, amsgrad off. */
-int orn_adam_step(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1,
-                  float beta2, float eps, int step, void *stream);
+ * p,g,m,v: n floats each.  step = 1-based global step.  weight decay 0, amsgrad off.
+ * Hyper-parameters are doubles (as Python holds them): 1-beta, lr/(1-beta1^t) and sqrt(1-beta2^t)
+ * are formed in double and rounded to fp32 once, exactly as torch.optim.Adam does. */
+int orn_adam_step(float *p, const float *g, float *m, float *v, size_t n, double lr, double beta1,
+                  double beta2, double eps, int step, void *stream);
 
 /* ---- A11  the whole per-frame training step as one engine           main_train.py:229-254 ----
  * The engine owns no memory: the caller passes four parameter-shaped arenas (params, grads, adam m,
@@ -124,7 +126,7 @@ typedef struct orn_engine_desc {
     int32_t sigmoid;                /* head activation (model.py:622) */
     int32_t loss_type;              /* ORN_LOSS_* */
     int32_t precision;              /* 0: fp32 everywhere; 1: bf16 activations / bf16 MFMA convs */
-    float beta1, beta2, eps;
+    double beta1, beta2, eps;
     int64_t stem_w0, stem_b0, stem_w1, stem_b1, head_w, head_b;
     int64_t n_params;               /* arena length in floats */
     orn_layer_desc layer[ORN_MAX_LAYERS];
