@@ -118,8 +118,8 @@ def cpu_baseline(steps=2):
     """The CPU oracle ("port": same ATen CPU ops as the reference's CPU path) timed on this host,
     bounded sample: 1 warm-up + `steps` ERB training steps at 720p with Fusion6."""
     from oracle import cpu_ref
-    ncores = os.cpu_count() or 1
-    torch.set_num_threads(ncores)
+    # the 1-GPU box's CPU share is 16 cores; oneDNN with all 256 hardware threads is pathologically slow
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
     sd = cpu_ref.init_state_dict(80, CFG['stem_dim_num'], CFG['fc_hw_dim'], CFG['strides'], CFG['expansion'],
                                  CFG['reduction'], CFG['lower_width'], 'ERB', seed=1)
     am = {k: torch.zeros_like(v) for k, v in sd.items()}

@@ -127,6 +127,9 @@ class TrainEngine:
         for blk in model.layers:
             Hs, Ws = Hs * blk.stride, Ws * blk.stride
         self.out_hw = (Hs, Ws)
+        # HIP graphs cannot be captured on the legacy default stream: the engine runs on its own
+        # stream, ordered against the caller's current stream on entry and exit.
+        self.stream = torch.cuda.Stream(device=dev)
 
     def __del__(self):
         h = getattr(self, '_h', None)
@@ -163,7 +166,9 @@ class TrainEngine:
         """Enqueue `n_steps` optimiser steps consuming the uploaded schedule (no host sync)."""
         if self.frames is None or self.sched is None:
             raise OrnError('set_video() and set_schedule() first')
-        st = _lib.stream()
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        st = c_void_p(self.stream.cuda_stream)
         if graph:
             check(lib().orn_engine_train_steps_graph(self._h, _lib.ptr(self.frames), _lib.ptr(self.embeds), _lib.ptr(self.sched),
                                                      _lib.ptr(self.cursor), _lib.ptr(self.stats_ring), c_int32(self.n_slots),
@@ -173,6 +178,7 @@ class TrainEngine:
                 check(lib().orn_engine_train_step(self._h, _lib.ptr(self.frames), _lib.ptr(self.embeds), _lib.ptr(self.sched),
                                                   _lib.ptr(self.cursor), _lib.ptr(self.stats_ring), c_int32(self.n_slots), st),
                       'orn_engine_train_step')
+        cur.wait_stream(self.stream)
         self.global_step += n_steps
 
     def stats(self, n: int) -> torch.Tensor:
