@@ -1,0 +1,826 @@
+// A4 fast path: the NeRVBlock conv (model.py:539,567) and its backward on bf16 MFMA
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulate) for the layers that carry 99 % of the step's FLOPs
+// (C_in % 96 == 0).  Activations live in HBM as channels-last bf16 with a one-pixel zero border:
+//
+//   xpad [H+2][W+2][C]      conv input  (= previous block's a = SiLU(z), border = conv zero padding)
+//   z    [Hs][Ws][Cn]       pre-activation after PixelShuffle (kept for SiLU')
+//   dypad[H+2][W+2][O']     gradient wrt the conv output, out-channel order o' = (i*s+j)*Cn + n so
+//                           that PixelShuffle / unshuffle move whole Cn-channel rows
+//   Wb   [9][O'][C]         merged kernel, bf16, tap-major, o' order        (forward B operand)
+//   Wd   [9][C][O']         flipped taps, transposed                        (dgrad B operand)
+//
+// conv (fwd and dgrad share one kernel): work-group = 8x32 output pixels; the (8+2)x(32+2) input
+// patch of a 96-channel chunk stays in LDS for all 9 taps (and all N tiles) -- each input byte is
+// read 1.33x instead of 9x -- while [BN][96] weight tiles stream from L2 through a double-buffered
+// LDS stage.  wgrad: work-group = 128 out channels x one kernel row (3 taps) x all 96 in-channels,
+// K = pixels, both operands pixel-major in LDS and read with ds_read_b64_tr_b16.
+#include "orn_common.h"
+
+typedef __bf16 h16;
+typedef __attribute__((ext_vector_type(8))) __bf16 h16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 h16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define MFMA_H16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+#define CB_TH 8
+#define CB_TW 32
+#define CB_PH (CB_TH + 2)
+#define CB_PW (CB_TW + 2)
+#define CB_CK 96                 // channels per K chunk
+#define CB_PIXB 208              // LDS bytes per patch pixel (192 data + 16 pad: conflict-free b128 reads)
+#define CB_PATCH_BYTES (CB_PH * CB_PW * CB_PIXB)
+#define CB_ROWB 208              // LDS bytes per weight-tile row
+
+enum { EPI_B_FWD = 0, EPI_B_DGRAD = 1, EPI_B_DGRAD_F32 = 2 };
+
+struct ConvBP {
+    const h16 *xpad;     // [H+2][W+2][Cin]
+    const h16 *w;        // [9][Nout][Cin]
+    const float *bias;   // [Nout] (o' order) or null
+    int H, W, Cin, Nout;
+    int tiles_w, tiles_h, n_tiles_per_wg;
+    // EPI_B_FWD
+    h16 *z;              // [H*s][W*s][Cn]
+    h16 *apad;           // [H*s+2][W*s+2][Cn] or null
+    int s, Cn;
+    // EPI_B_DGRAD: out = dx * silu'(zprev) scattered into the previous layer's dypad
+    const h16 *zprev;    // [H][W][Nout]
+    h16 *dyprev;         // [H/sp+2][W/sp+2][Nout*sp*sp]
+    int sp;
+    // EPI_B_DGRAD_F32
+    float *dx_f32;       // [H][W][Nout]
+};
+
+template <int WAVES_M, int WAVES_N, int MB, int NB, int EPI>
+__global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP p)
+{
+    constexpr int NT = WAVES_M * WAVES_N * 64;
+    constexpr int BN = WAVES_N * NB * 32;
+    static_assert(WAVES_M * MB == CB_TH, "M tile must be 8 rows of 32 pixels");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *patch = smem;
+    unsigned char *bs0 = smem + CB_PATCH_BYTES;
+    constexpr int BS_BYTES = BN * CB_ROWB;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int tile = blockIdx.x;
+    const int tw = tile % p.tiles_w, th = tile / p.tiles_w;
+    const int h0 = th * CB_TH, w0 = tw * CB_TW;
+    const int H = p.H, W = p.W, Cin = p.Cin;
+    const int Q = Cin / CB_CK;
+    const int nt0 = blockIdx.y * p.n_tiles_per_wg;
+    const int n_tiles = Q * 9;                         // weight tiles per N tile
+
+    constexpr int B_CHUNKS = BN * 12;                  // 16-byte chunks per weight tile
+    constexpr int B_PER_THR = (B_CHUNKS + NT - 1) / NT;
+    u32x4 breg[B_PER_THR];
+
+    // weight-tile staging through registers (macros, not lambdas: the register array must stay in VGPRs)
+#define LOAD_B(nt_, q_, tap_)                                                                                   \
+    _Pragma("unroll") for (int it = 0; it < B_PER_THR; ++it) {                                                  \
+        const int idx = t + it * NT;                                                                            \
+        if (B_CHUNKS % NT == 0 || idx < B_CHUNKS) {                                                             \
+            const int row = idx / 12, ch = idx - row * 12;                                                      \
+            breg[it] = *reinterpret_cast<const u32x4 *>(                                                        \
+                p.w + ((size_t)((tap_) * p.Nout + (nt_) * BN + row) * Cin + (q_) * CB_CK + ch * 8));            \
+        }                                                                                                       \
+    }
+#define STORE_B(buf_)                                                                                           \
+    _Pragma("unroll") for (int it = 0; it < B_PER_THR; ++it) {                                                  \
+        const int idx = t + it * NT;                                                                            \
+        if (B_CHUNKS % NT == 0 || idx < B_CHUNKS) {                                                             \
+            const int row = idx / 12, ch = idx - row * 12;                                                      \
+            *reinterpret_cast<u32x4 *>(bs0 + (buf_) * BS_BYTES + row * CB_ROWB + ch * 16) = breg[it];           \
+        }                                                                                                       \
+    }
+    auto stage_patch = [&](int q) {
+        for (int idx = t; idx < CB_PH * CB_PW * 12; idx += NT) {
+            const int pix = idx / 12, ch = idx - pix * 12;
+            const int pr = pix / CB_PW, pc = pix - pr * CB_PW;
+            const int gh = h0 + pr, gw = w0 + pc;          // padded coords
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (gh < H + 2 && gw < W + 2)
+                v = *reinterpret_cast<const uint4 *>(p.xpad + ((size_t)gh * (W + 2) + gw) * Cin + q * CB_CK + ch * 8);
+            *reinterpret_cast<uint4 *>(patch + pix * CB_PIXB + ch * 16) = v;
+        }
+    };
+
+    for (int nti = 0; nti < p.n_tiles_per_wg; ++nti) {
+        const int nt = nt0 + nti;
+        f32x16 acc[MB][NB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        // prologue: first weight tile (+ patch when it is not already resident)
+        LOAD_B(nt, 0, 0)
+        if (nti == 0 || Q > 1) {
+            __syncthreads();
+            stage_patch(0);
+        }
+        STORE_B(0)
+        __syncthreads();
+        int cur = 0;
+        for (int tt = 0; tt < n_tiles; ++tt) {
+            const int q = tt / 9, tap = tt - q * 9;
+            const int ti = tap / 3, tj = tap - ti * 3;
+            const bool has_next = (tt + 1 < n_tiles);
+            const int qn = (tt + 1) / 9, tapn = (tt + 1) - qn * 9;
+            if (has_next) { LOAD_B(nt, qn, tapn) }
+            const unsigned char *bsb = bs0 + cur * BS_BYTES + (wn * NB * 32 + l31) * CB_ROWB + hh * 16;
+            const unsigned char *pa = patch + ((wm * MB + ti) * CB_PW + (l31 + tj)) * CB_PIXB + hh * 16;
+#pragma unroll
+            for (int ks = 0; ks < CB_CK / 16; ++ks) {
+                h16x8 a[MB], b[NB];
+#pragma unroll
+                for (int i = 0; i < MB; ++i) a[i] = *reinterpret_cast<const h16x8 *>(pa + i * CB_PW * CB_PIXB + ks * 32);
+#pragma unroll
+                for (int j = 0; j < NB; ++j) b[j] = *reinterpret_cast<const h16x8 *>(bsb + j * 32 * CB_ROWB + ks * 32);
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) acc[i][j] = MFMA_H16(a[i], b[j], acc[i][j]);
+            }
+            if (has_next) {
+                if (qn != q) {            // next chunk needs a new patch: everyone must be done reading
+                    __syncthreads();
+                    stage_patch(qn);
+                }
+                STORE_B(cur ^ 1)
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+
+        // ---- epilogue --------------------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int gh = h0 + wm * MB + i;
+            if (gh >= H) continue;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int oc = nt * BN + (wn * NB + j) * 32 + l31;       // output channel (o' for fwd)
+                float bv = 0.f;
+                if (EPI == EPI_B_FWD && p.bias) bv = p.bias[oc];
+                int ij = 0, n = 0, si = 0, sj = 0;
+                if (EPI == EPI_B_FWD) { ij = oc / p.Cn; n = oc - ij * p.Cn; si = ij / p.s; sj = ij - si * p.s; }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int gw = w0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                    if (gw >= W) continue;
+                    const float v = acc[i][j][reg] + bv;
+                    if (EPI == EPI_B_FWD) {
+                        const int Hs = H * p.s, Ws = W * p.s;
+                        const int oh = gh * p.s + si, ow = gw * p.s + sj;
+                        (void)Hs;
+                        p.z[((size_t)oh * Ws + ow) * p.Cn + n] = (h16)v;
+                        if (p.apad) p.apad[((size_t)(oh + 1) * (Ws + 2) + (ow + 1)) * p.Cn + n] = (h16)orn_silu(v);
+                    } else if (EPI == EPI_B_DGRAD) {
+                        const float zz = (float)p.zprev[((size_t)gh * W + gw) * p.Nout + oc];
+                        const int sp = p.sp;
+                        const int ph = gh / sp, pw = gw / sp;
+                        const int sub = (gh - ph * sp) * sp + (gw - pw * sp);
+                        p.dyprev[((size_t)(ph + 1) * (W / sp + 2) + (pw + 1)) * (p.Nout * sp * sp) + sub * p.Nout + oc] =
+                            (h16)(v * orn_silu_grad(zz));
+                    } else {
+                        p.dx_f32[((size_t)gh * W + gw) * p.Nout + oc] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+#undef LOAD_B
+#undef STORE_B
+
+template <int WAVES_M, int WAVES_N, int MB, int NB, int EPI>
+static int launch_conv_cfg(const ConvBP &p, int n_tiles_total, hipStream_t st)
+{
+    constexpr int BN = WAVES_N * NB * 32;
+    constexpr int NT = WAVES_M * WAVES_N * 64;
+    const size_t smem = CB_PATCH_BYTES + 2 * (size_t)BN * CB_ROWB;
+    auto kern = k_conv_nhwc_bf16<WAVES_M, WAVES_N, MB, NB, EPI>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) { orn_set_error("conv_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_done = true;
+    }
+    dim3 grid(p.tiles_w * p.tiles_h, n_tiles_total / p.n_tiles_per_wg);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), smem, st, p);
+    ORN_LAUNCH_CHECK("conv_nhwc_bf16");
+    return 0;
+}
+
+// fwd: N tile 128 (waves 4x2, wave tile 64 px x 64 ch); dgrad: N = 96 in one tile (waves 8x1, 32 px x 96 ch)
+int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p, int H, int W, int Cin, int O, int s,
+                             h16 *z, h16 *apad, hipStream_t st)
+{
+    ORN_REQUIRE(Cin % CB_CK == 0 && O % 128 == 0 && O % (s * s) == 0, "conv_bf16_fwd: unsupported Cin=%d O=%d s=%d", Cin, O, s);
+    ConvBP p = {};
+    p.xpad = xpad; p.w = wb; p.bias = bias_p; p.H = H; p.W = W; p.Cin = Cin; p.Nout = O;
+    p.tiles_w = orn_cdiv(W, CB_TW); p.tiles_h = orn_cdiv(H, CB_TH);
+    p.z = z; p.apad = apad; p.s = s; p.Cn = O / (s * s);
+    const int nt_total = O / 128;
+    // few pixel tiles: spread the N tiles over work-groups to fill the chip
+    p.n_tiles_per_wg = (p.tiles_w * p.tiles_h >= 512) ? nt_total : 1;
+    return launch_conv_cfg<4, 2, 2, 2, EPI_B_FWD>(p, nt_total, st);
+}
+
+int orn_launch_conv_bf16_dgrad(const h16 *dypad, const h16 *wd, int H, int W, int O, int C, const h16 *zprev,
+                               h16 *dyprev, int sp, float *dx_f32, hipStream_t st)
+{
+    ORN_REQUIRE(O % CB_CK == 0 && C == 96, "conv_bf16_dgrad: unsupported O=%d C=%d", O, C);
+    ConvBP p = {};
+    p.xpad = dypad; p.w = wd; p.bias = nullptr; p.H = H; p.W = W; p.Cin = O; p.Nout = C;
+    p.tiles_w = orn_cdiv(W, CB_TW); p.tiles_h = orn_cdiv(H, CB_TH);
+    p.n_tiles_per_wg = 1;
+    p.zprev = zprev; p.dyprev = dyprev; p.sp = sp; p.dx_f32 = dx_f32;
+    if (dx_f32) return launch_conv_cfg<8, 1, 1, 3, EPI_B_DGRAD_F32>(p, 1, st);
+    ORN_REQUIRE(zprev && dyprev && sp >= 1 && H % sp == 0 && W % sp == 0, "conv_bf16_dgrad: bad epilogue arguments");
+    return launch_conv_cfg<8, 1, 1, 3, EPI_B_DGRAD>(p, 1, st);
+}
+
+// ================================================================================================
+// wgrad: dW[tap][o'][c] = sum_p dy[p][o'] * x[p + off(tap)][c]
+// ================================================================================================
+#define WB_TH 4
+#define WB_TW 32
+#define WB_NPX (WB_TH * WB_TW)
+#define WB_BO 128
+#define WB_DYB 320               // LDS bytes per dy pixel row (256 data + 64 pad: conflict-free tr reads)
+#define WB_XB 192                // LDS bytes per x pixel (96 ch, unpadded: conflict-free tr reads)
+#define WB_XW (WB_TW + 2)
+#define WB_DY_BYTES (WB_NPX * WB_DYB)
+#define WB_X_BYTES (WB_TH * WB_XW * WB_XB)
+
+struct WgradBP {
+    const h16 *xpad;    // [H+2][W+2][96]
+    const h16 *dypad;   // [H+2][W+2][O]
+    float *slabs;       // [S][9][O][96]
+    int H, W, O;
+    int tiles_w, n_ktiles, S, n_otiles;
+};
+
+__device__ __forceinline__ h16x8 tr_frag(const unsigned char *base0, const unsigned char *base1)
+{
+    // two transposed 4x16 block reads -> the 8 K-consecutive elements of this lane's row/column
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(base0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(base1));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(h16x8, v);
+}
+
+__global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *dys = smem;
+    unsigned char *xs = smem + WB_DY_BYTES;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int g = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
+    // XCD-aware decode: the 9 work-groups that share one pixel range sit on one XCD (speed only)
+    const int id = blockIdx.x;
+    const int xcd = id & 7, qx = id >> 3;
+    const int sub = qx % (3 * p.n_otiles), sidx = (qx / (3 * p.n_otiles)) * 8 + xcd;
+    const int ti = sub % 3, ot = sub / 3;
+    const int o0 = ot * WB_BO;
+    const int H = p.H, W = p.W, O = p.O;
+
+    f32x16 acc[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][c][r] = 0.f;
+
+    // per-lane transposed-read offsets (pixel part is added per K slice)
+    const int a_off = (8 * (g >> 1) + lq) * WB_DYB + (wave * 32 + 16 * (g & 1) + 4 * lp) * 2;
+    const int b_off = (8 * (g >> 1) + lq) * WB_XB + (16 * (g & 1) + 4 * lp) * 2;
+
+    for (int kt = sidx; kt < p.n_ktiles; kt += p.S) {
+        const int th = kt / p.tiles_w, tw = kt - th * p.tiles_w;
+        const int h0 = th * WB_TH, w0 = tw * WB_TW;
+        __syncthreads();
+        for (int idx = t; idx < WB_NPX * 16; idx += 256) {
+            const int px = idx >> 4, ch = idx & 15;
+            const int r = px / WB_TW, c = px - r * WB_TW;
+            const int gh = h0 + r, gw = w0 + c;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (gh < H && gw < W) v = *reinterpret_cast<const uint4 *>(p.dypad + ((size_t)(gh + 1) * (W + 2) + (gw + 1)) * O + o0 + ch * 8);
+            *reinterpret_cast<uint4 *>(dys + px * WB_DYB + ch * 16) = v;
+        }
+        for (int idx = t; idx < WB_TH * WB_XW * 12; idx += 256) {
+            const int px = idx / 12, ch = idx - px * 12;
+            const int r = px / WB_XW, c = px - r * WB_XW;
+            const int gh = h0 + r + ti, gw = w0 + c;          // padded coords of x
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (gh < H + 2 && gw < W + 2) v = *reinterpret_cast<const uint4 *>(p.xpad + ((size_t)gh * (W + 2) + gw) * 96 + ch * 8);
+            *reinterpret_cast<uint4 *>(xs + px * WB_XB + ch * 16) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < WB_TH; ++r)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const unsigned char *ap = dys + (r * WB_TW + 16 * half) * WB_DYB + a_off;
+                const h16x8 a = tr_frag(ap, ap + 4 * WB_DYB);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const unsigned char *bp = xs + (r * WB_XW + 16 * half + j) * WB_XB + b_off;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const h16x8 b = tr_frag(bp + c * 64, bp + c * 64 + 4 * WB_XB);
+                        acc[j][c] = MFMA_H16(a, b, acc[j][c]);
+                    }
+                }
+            }
+    }
+    float *out = p.slabs + (size_t)sidx * 9 * O * 96;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int o = o0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                out[((size_t)(ti * 3 + j) * O + o) * 96 + c * 32 + l31] = acc[j][c][reg];
+            }
+}
+
+// dWf[o][c][i][j] = gscale * sum_s slabs[s][tap][o'(o)][c],  o' = (o % s2)*Cn + o / s2
+__global__ void k_wgrad_bf16_reduce(const float *__restrict__ slabs, int S, int O, int Cn, int s2, float gscale,
+                                    float *__restrict__ dwf)
+{
+    const size_t n = (size_t)9 * O * 96;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += slabs[(size_t)s * n + idx];
+    const int c = (int)(idx % 96);
+    const size_t r = idx / 96;
+    const int op = (int)(r % O), tap = (int)(r / O);
+    const int ij = op / Cn, nn = op - ij * Cn;
+    const int o = nn * s2 + ij;
+    dwf[((size_t)o * 96 + c) * 9 + tap] = acc * gscale;
+}
+
+int orn_wgrad_bf16_split(int H, int W, int O)
+{
+    const int n_ktiles = orn_cdiv(H, WB_TH) * orn_cdiv(W, WB_TW);
+    const int per = 3 * (O / WB_BO);
+    int S = (512 / per) / 8 * 8;
+    if (S < 8) S = 8;
+    while (S > 8 && S > n_ktiles) S -= 8;
+    return S;
+}
+
+size_t orn_wgrad_bf16_ws_floats(int H, int W, int O) { return (size_t)orn_wgrad_bf16_split(H, W, O) * 9 * O * 96; }
+
+int orn_launch_wgrad_bf16(const h16 *xpad, const h16 *dypad, int H, int W, int C, int O, int s, float gscale,
+                          float *slabs, float *dwf, hipStream_t st)
+{
+    ORN_REQUIRE(C == 96 && O % WB_BO == 0 && O % (s * s) == 0, "wgrad_bf16: unsupported C=%d O=%d", C, O);
+    WgradBP p;
+    p.xpad = xpad; p.dypad = dypad; p.slabs = slabs; p.H = H; p.W = W; p.O = O;
+    p.tiles_w = orn_cdiv(W, WB_TW);
+    p.n_ktiles = p.tiles_w * orn_cdiv(H, WB_TH);
+    p.S = orn_wgrad_bf16_split(H, W, O);
+    p.n_otiles = O / WB_BO;
+    static bool attr_done = false;
+    const size_t smem = WB_DY_BYTES + WB_X_BYTES;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_wgrad_nhwc_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) { orn_set_error("wgrad_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_wgrad_nhwc_bf16, dim3(3 * p.n_otiles * p.S), dim3(256), smem, st, p);
+    ORN_LAUNCH_CHECK("wgrad_nhwc_bf16");
+    const size_t n = (size_t)9 * O * 96;
+    hipLaunchKernelGGL(k_wgrad_bf16_reduce, dim3(orn_cdiv((long)n, 256)), dim3(256), 0, st, slabs, p.S, O, O / (s * s), s * s,
+                       gscale, dwf);
+    ORN_LAUNCH_CHECK("wgrad_bf16_reduce");
+    return 0;
+}
+
+// ================================================================================================
+// format helpers
+// ================================================================================================
+// Wf fp32 [O][C][3][3] -> Wb bf16 [9][O'][C] (o' = (o % s2)*Cn + o / s2), Wd bf16 [9][C][O'] with
+// flipped taps (tap' = 8 - tap), bias' [O'].
+__global__ void k_prep_weights_bf16(const float *__restrict__ wf, const float *__restrict__ bf, int O, int C, int Cn, int s2,
+                                    h16 *__restrict__ wb, h16 *__restrict__ wd, float *__restrict__ bias_p)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (size_t)O) {
+        const int o = (int)idx;
+        bias_p[(o % s2) * Cn + o / s2] = bf[o];
+    }
+    if (idx >= (size_t)O * C * 9) return;
+    const int tap = (int)(idx % 9);
+    const size_t oc = idx / 9;
+    const int c = (int)(oc % C), o = (int)(oc / C);
+    const int op = (o % s2) * Cn + o / s2;
+    const h16 v = (h16)wf[idx];
+    wb[((size_t)tap * O + op) * C + c] = v;
+    wd[((size_t)(8 - tap) * C + c) * O + op] = v;
+}
+
+int orn_launch_prep_weights_bf16(const float *wf, const float *bf, int O, int C, int s, h16 *wb, h16 *wd, float *bias_p,
+                                 hipStream_t st)
+{
+    hipLaunchKernelGGL(k_prep_weights_bf16, dim3(orn_cdiv((long)O * C * 9, 256)), dim3(256), 0, st, wf, bf, O, C, O / (s * s),
+                       s * s, wb, wd, bias_p);
+    ORN_LAUNCH_CHECK("prep_weights_bf16");
+    return 0;
+}
+
+// fp32 NCHW [C][H][W] -> bf16 padded NHWC [H+2][W+2][C] interior (border stays zero)
+__global__ void k_nchw_to_nhwc_pad_bf16(const float *__restrict__ src, int C, int H, int W, h16 *__restrict__ dst)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)C * H * W) return;
+    const int c = (int)(idx % C);
+    const size_t pix = idx / C;
+    const int w = (int)(pix % W), h = (int)(pix / W);
+    dst[((size_t)(h + 1) * (W + 2) + (w + 1)) * C + c] = (h16)src[((size_t)c * H + h) * W + w];
+}
+
+// fp32 NHWC [H][W][C] -> fp32 NCHW [C][H][W]
+__global__ void k_nhwc_to_nchw_f32(const float *__restrict__ src, int C, int H, int W, float *__restrict__ dst)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)C * H * W) return;
+    const size_t HW = (size_t)H * W;
+    const int c = (int)(idx / HW);
+    const size_t pix = idx - (size_t)c * HW;
+    dst[idx] = src[pix * C + c];
+}
+
+int orn_launch_nchw_to_nhwc_pad_bf16(const float *src, int C, int H, int W, h16 *dst, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_nchw_to_nhwc_pad_bf16, dim3(orn_cdiv((long)C * H * W, 256)), dim3(256), 0, st, src, C, H, W, dst);
+    ORN_LAUNCH_CHECK("nchw_to_nhwc_pad_bf16");
+    return 0;
+}
+
+int orn_launch_nhwc_to_nchw_f32(const float *src, int C, int H, int W, float *dst, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_nhwc_to_nchw_f32, dim3(orn_cdiv((long)C * H * W, 256)), dim3(256), 0, st, src, C, H, W, dst);
+    ORN_LAUNCH_CHECK("nhwc_to_nchw_f32");
+    return 0;
+}
+
+// dbias: partial[blk][o'] = sum over the block's pixel rows of dypad interior; then reduced + un-permuted
+#define DB_MAXO 1536
+__global__ void __launch_bounds__(256) k_dbias_nhwc_partial(const h16 *__restrict__ dypad, int H, int W, int O, int rows_per_blk,
+                                                            float *__restrict__ partial)
+{
+    __shared__ float red[DB_MAXO];
+    const int o8 = O / 8;                       // 16-byte groups per pixel
+    const int nw = 256 / o8;                    // pixel lanes
+    const int grp = threadIdx.x % o8, lw = threadIdx.x / o8;
+    const int h_begin = blockIdx.x * rows_per_blk, h_end = min(H, h_begin + rows_per_blk);
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (lw < nw)
+        for (int h = h_begin; h < h_end; ++h) {
+            const h16 *row = dypad + ((size_t)(h + 1) * (W + 2) + 1) * O + grp * 8;
+            for (int w = lw; w < W; w += nw) {
+                const h16x8 v = *reinterpret_cast<const h16x8 *>(row + (size_t)w * O);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s[k] += (float)v[k];
+            }
+        }
+    for (int i = threadIdx.x; i < O; i += 256) red[i] = 0.f;
+    __syncthreads();
+    for (int r = 0; r < nw; ++r) {              // fixed order: deterministic
+        if (lw == r)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) red[grp * 8 + k] += s[k];
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < O; i += 256) partial[(size_t)blockIdx.x * O + i] = red[i];
+}
+
+__global__ void k_dbias_finish(const float *__restrict__ partial, int nblk, int O, int Cn, int s2, float gscale,
+                               float *__restrict__ dbf)
+{
+    const int op = blockIdx.x * blockDim.x + threadIdx.x;
+    if (op >= O) return;
+    float acc = 0.f;
+    for (int b = 0; b < nblk; ++b) acc += partial[(size_t)b * O + op];
+    const int ij = op / Cn, nn = op - ij * Cn;
+    dbf[nn * s2 + ij] = acc * gscale;
+}
+
+size_t orn_dbias_bf16_ws_floats(int H, int O) { return (size_t)orn_cdiv(H, 2) * O; }
+
+int orn_launch_dbias_bf16(const h16 *dypad, int H, int W, int O, int s, float gscale, float *partial, float *dbf, hipStream_t st)
+{
+    ORN_REQUIRE(O % 8 == 0 && O / 8 <= 256 && O <= DB_MAXO, "dbias_bf16: unsupported O=%d", O);
+    const int rows_per_blk = 2, nblk = orn_cdiv(H, rows_per_blk);
+    hipLaunchKernelGGL(k_dbias_nhwc_partial, dim3(nblk), dim3(256), 0, st, dypad, H, W, O, rows_per_blk, partial);
+    ORN_LAUNCH_CHECK("dbias_partial");
+    hipLaunchKernelGGL(k_dbias_finish, dim3(orn_cdiv(O, 128)), dim3(128), 0, st, partial, nblk, O, O / (s * s), s * s, gscale, dbf);
+    ORN_LAUNCH_CHECK("dbias_finish");
+    return 0;
+}
+
+// ================================================================================================
+// A5 head on the channels-last bf16 pre-activation of the last block (model.py:621-622):
+//   a = SiLU(z);  u = W a + b;  out = (tanh u + 1)/2 | sigmoid u           out: fp32 NCHW [3][H][W]
+// 4 lanes per pixel (C/4 channels each, 16-byte loads), 16 pixels per wave: fully coalesced.
+// ================================================================================================
+#define HB_MAXC 256
+
+__global__ void __launch_bounds__(256)
+k_head_fwd_nhwc_bf16(const h16 *__restrict__ z, const float *__restrict__ w, const float *__restrict__ bias, int C, size_t HW,
+                     int sigmoid, float *__restrict__ out)
+{
+    __shared__ float sw[3 * HB_MAXC + 3];
+    for (int i = threadIdx.x; i < 3 * C; i += 256) sw[i] = w[i];
+    if (threadIdx.x < 3) sw[3 * C + threadIdx.x] = bias[threadIdx.x];
+    __syncthreads();
+    const int sub = threadIdx.x & 3;
+    const int nq = C / 32;
+    for (size_t pix = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2); pix < HW; pix += (size_t)gridDim.x * 64) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int q = 0; q < nq; ++q) {
+            const int c0 = (q * 4 + sub) * 8;
+            const h16x8 v = *reinterpret_cast<const h16x8 *>(z + pix * C + c0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a = orn_silu((float)v[e]);
+                a0 = fmaf(sw[c0 + e], a, a0);
+                a1 = fmaf(sw[C + c0 + e], a, a1);
+                a2 = fmaf(sw[2 * C + c0 + e], a, a2);
+            }
+        }
+        a0 += __shfl_xor(a0, 1, 64); a1 += __shfl_xor(a1, 1, 64); a2 += __shfl_xor(a2, 1, 64);
+        a0 += __shfl_xor(a0, 2, 64); a1 += __shfl_xor(a1, 2, 64); a2 += __shfl_xor(a2, 2, 64);
+        if (sub < 3) {
+            const float u = (sub == 0 ? a0 : (sub == 1 ? a1 : a2)) + sw[3 * C + sub];
+            out[(size_t)sub * HW + pix] = sigmoid ? 1.0f / (1.0f + __expf(-u)) : (tanhf(u) + 1.0f) * 0.5f;
+        }
+    }
+}
+
+// Backward: du = dout * act'(out); dz = (W^T du) * SiLU'(z) -> previous-layer dypad layout (bf16);
+// dW[k][c] += du[k]*SiLU(z[c]); db[k] += du[k].  partial[blk][3*C+3], reduced afterwards.
+template <int NQ>
+__global__ void __launch_bounds__(256)
+k_head_bwd_nhwc_bf16(const h16 *__restrict__ z, const float *__restrict__ w, const float *__restrict__ out,
+                     const float *__restrict__ dout, int H, int W, int sigmoid, int sp, h16 *__restrict__ dypad,
+                     float *__restrict__ partial)
+{
+    constexpr int C = NQ * 32;
+    __shared__ float sw[3 * C];
+    __shared__ float sred[4][4][NQ * 24 + 3];
+    for (int i = threadIdx.x; i < 3 * C; i += 256) sw[i] = w[i];
+    __syncthreads();
+    const int sub = threadIdx.x & 3, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t HW = (size_t)H * W;
+    float dwacc[NQ][8][3];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dwacc[q][e][0] = 0.f; dwacc[q][e][1] = 0.f; dwacc[q][e][2] = 0.f; }
+    float dbacc[3] = {0.f, 0.f, 0.f};
+    const int Wp = W / sp + 2, Cp = C * sp * sp;
+    for (size_t pix = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2); pix < HW; pix += (size_t)gridDim.x * 64) {
+        float du[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float o = out[(size_t)k * HW + pix], g = dout[(size_t)k * HW + pix];
+            du[k] = g * (sigmoid ? o * (1.0f - o) : 2.0f * o * (1.0f - o));
+            dbacc[k] += du[k];
+        }
+        const int h = (int)(pix / W), ww = (int)(pix - (size_t)h * W);
+        const int ph = h / sp, pw = ww / sp;
+        h16 *dst = dypad + ((size_t)(ph + 1) * Wp + (pw + 1)) * Cp + ((h - ph * sp) * sp + (ww - pw * sp)) * C;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c0 = (q * 4 + sub) * 8;
+            const h16x8 v = *reinterpret_cast<const h16x8 *>(z + pix * C + c0);
+            h16x8 o8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float zz = (float)v[e];
+                const float sg = 1.0f / (1.0f + __expf(-zz));
+                const float a = zz * sg;
+                const float da = fmaf(sw[2 * C + c0 + e], du[2], fmaf(sw[C + c0 + e], du[1], sw[c0 + e] * du[0]));
+                o8[e] = (h16)(da * (sg * (1.0f + zz * (1.0f - sg))));
+                dwacc[q][e][0] = fmaf(du[0], a, dwacc[q][e][0]);
+                dwacc[q][e][1] = fmaf(du[1], a, dwacc[q][e][1]);
+                dwacc[q][e][2] = fmaf(du[2], a, dwacc[q][e][2]);
+            }
+            *reinterpret_cast<h16x8 *>(dst + c0) = o8;
+        }
+    }
+    // reduce over the 16 pixel slots of the wave (lanes with equal sub), fixed butterfly order
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float v = dwacc[q][e][k];
+                v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                if (lane < 4) sred[wave][sub][(q * 8 + e) * 3 + k] = v;
+            }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float v = dbacc[k];
+        v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        if (lane < 4) sred[wave][sub][NQ * 24 + k] = v;
+    }
+    __syncthreads();
+    float *pout = partial + (size_t)blockIdx.x * (3 * C + 3);
+    for (int i = threadIdx.x; i < 3 * C; i += 256) {
+        const int k = i / C, c = i - k * C;
+        const int grp = c / 8, e = c - grp * 8, q = grp / 4, sb = grp - q * 4;
+        const int ri = (q * 8 + e) * 3 + k;
+        pout[i] = (sred[0][sb][ri] + sred[1][sb][ri]) + (sred[2][sb][ri] + sred[3][sb][ri]);
+    }
+    if (threadIdx.x < 3) {
+        const int ri = NQ * 24 + threadIdx.x;
+        // every sub lane accumulated the same du: take sub 0
+        pout[3 * C + threadIdx.x] = (sred[0][0][ri] + sred[1][0][ri]) + (sred[2][0][ri] + sred[3][0][ri]);
+    }
+}
+
+__global__ void k_head_bf16_finish(const float *__restrict__ red, int C, float gscale, float *__restrict__ dw, float *__restrict__ db)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * C) dw[i] = red[i] * gscale;
+    else if (i < 3 * C + 3) db[i - 3 * C] = red[i] * gscale;
+}
+
+#define HB_BLOCKS 1024
+
+int orn_launch_head_fwd_bf16(const h16 *z, const float *w, const float *b, int C, size_t HW, int sigmoid, float *out, hipStream_t st)
+{
+    ORN_REQUIRE(C % 32 == 0 && C <= HB_MAXC, "head_bf16: unsupported C=%d", C);
+    int blocks = orn_cdiv((long)HW, 64);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_head_fwd_nhwc_bf16, dim3(blocks), dim3(256), 0, st, z, w, b, C, HW, sigmoid, out);
+    ORN_LAUNCH_CHECK("head_fwd_bf16");
+    return 0;
+}
+
+size_t orn_head_bwd_bf16_ws_floats(int C) { return (size_t)(HB_BLOCKS + 1) * (3 * C + 3); }
+
+int orn_launch_head_bwd_bf16(const h16 *z, const float *w, const float *out, const float *dout, int C, int H, int W, int sigmoid,
+                             int sp, float gscale, h16 *dypad, float *dw, float *db, float *ws, hipStream_t st)
+{
+    ORN_REQUIRE(C == 96 || C == 32 || C == 64 || C == 128, "head_bwd_bf16: unsupported C=%d", C);
+    ORN_REQUIRE(H % sp == 0 && W % sp == 0, "head_bwd_bf16: H,W not divisible by stride");
+    int blocks = orn_cdiv((long)H * W, 64);
+    if (blocks > HB_BLOCKS) blocks = HB_BLOCKS;
+    float *partial = ws, *red = ws + (size_t)HB_BLOCKS * (3 * C + 3);
+    switch (C) {
+    case 32: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<1>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, dypad, partial); break;
+    case 64: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<2>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, dypad, partial); break;
+    case 96: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<3>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, dypad, partial); break;
+    default: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<4>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, dypad, partial); break;
+    }
+    ORN_LAUNCH_CHECK("head_bwd_bf16");
+    const size_t n = 3 * (size_t)C + 3;
+    ORN_TRY(orn_launch_reduce_rows(partial, blocks, n, n, red, st));
+    hipLaunchKernelGGL(k_head_bf16_finish, dim3(orn_cdiv((long)n, 128)), dim3(128), 0, st, red, C, gscale, dw, db);
+    ORN_LAUNCH_CHECK("head_bf16_finish");
+    return 0;
+}
+
+// ================================================================================================
+// test / per-op hooks: the bf16 block on PyTorch-layout fp32 tensors (conversions included)
+// ================================================================================================
+// bf16 NHWC [H][W][C] (optionally padded source) -> fp32 NCHW
+__global__ void k_nhwc_bf16_to_nchw_f32(const h16 *__restrict__ src, int C, int H, int W, int pad, float *__restrict__ dst)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)C * H * W) return;
+    const size_t HW = (size_t)H * W;
+    const int c = (int)(idx / HW);
+    const size_t pix = idx - (size_t)c * HW;
+    const int h = (int)(pix / W), w = (int)(pix - (size_t)h * W);
+    dst[idx] = (float)src[((size_t)(h + pad) * (W + 2 * pad) + (w + pad)) * C + c];
+}
+
+// fp32 NCHW z, da [Cn][Hs][Ws] -> z bf16 NHWC and dypad = unshuffle(da * SiLU'(z)) (o' order, padded)
+__global__ void k_make_dy_bf16(const float *__restrict__ z, const float *__restrict__ da, int Cn, int H, int W, int s,
+                               h16 *__restrict__ zb, h16 *__restrict__ dypad)
+{
+    const size_t n = (size_t)Cn * H * s * W * s;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int Hs = H * s, Ws = W * s;
+    const int c = (int)(idx % Cn);
+    const size_t pix = idx / Cn;
+    const int ow = (int)(pix % Ws), oh = (int)(pix / Ws);
+    const size_t src = ((size_t)c * Hs + oh) * Ws + ow;
+    const h16 zq = (h16)z[src];
+    zb[pix * Cn + c] = zq;
+    const int ph = oh / s, pw = ow / s, sub = (oh - ph * s) * s + (ow - pw * s);
+    dypad[((size_t)(ph + 1) * (W + 2) + (pw + 1)) * ((size_t)Cn * s * s) + (size_t)sub * Cn + c] =
+        (h16)(da[src] * orn_silu_grad((float)zq));
+}
+
+static inline size_t alh(size_t halfs) { return orn_align(halfs * 2) / 2; }
+
+extern "C" size_t orn_conv3x3_ps_silu_bf16_ws_bytes(int C, int O, int H, int W, int s)
+{
+    const size_t Hs = (size_t)H * s, Ws = (size_t)W * s, Cn = O / (s * s);
+    size_t b = 0;
+    b += alh((size_t)(H + 2) * (W + 2) * C) * 2;          // xpad
+    b += 2 * alh((size_t)9 * O * C) * 2;                  // wb, wd
+    b += orn_align((size_t)O * 4);                        // bias'
+    b += alh(Hs * Ws * Cn) * 2;                           // z bf16
+    b += alh((Hs + 2) * (Ws + 2) * Cn) * 2;               // apad
+    b += alh((size_t)(H + 2) * (W + 2) * O) * 2;          // dypad
+    b += orn_align(orn_wgrad_bf16_ws_floats(H, W, O) * 4);
+    b += orn_align(orn_dbias_bf16_ws_floats(H, O) * 4);
+    b += orn_align((size_t)H * W * C * 4);                // dx fp32 NHWC
+    return b;
+}
+
+struct Bf16Ws {
+    h16 *xpad, *wb, *wd, *zb, *apad, *dypad;
+    float *biasp, *slabs, *dbp, *dxn;
+};
+
+static Bf16Ws carve_bf16(void *ws, int C, int O, int H, int W, int s)
+{
+    const size_t Hs = (size_t)H * s, Ws = (size_t)W * s, Cn = O / (s * s);
+    unsigned char *p = (unsigned char *)ws;
+    Bf16Ws r;
+    r.xpad = (h16 *)p; p += alh((size_t)(H + 2) * (W + 2) * C) * 2;
+    r.wb = (h16 *)p; p += alh((size_t)9 * O * C) * 2;
+    r.wd = (h16 *)p; p += alh((size_t)9 * O * C) * 2;
+    r.biasp = (float *)p; p += orn_align((size_t)O * 4);
+    r.zb = (h16 *)p; p += alh(Hs * Ws * Cn) * 2;
+    r.apad = (h16 *)p; p += alh((Hs + 2) * (Ws + 2) * Cn) * 2;
+    r.dypad = (h16 *)p; p += alh((size_t)(H + 2) * (W + 2) * O) * 2;
+    r.slabs = (float *)p; p += orn_align(orn_wgrad_bf16_ws_floats(H, W, O) * 4);
+    r.dbp = (float *)p; p += orn_align(orn_dbias_bf16_ws_floats(H, O) * 4);
+    r.dxn = (float *)p;
+    return r;
+}
+
+// Same contract as orn_conv3x3_ps_silu_fwd (B = 1) but computed on the bf16 MFMA path.
+// `ws` must be zero-filled by the caller before the first use (the padded borders are never written).
+extern "C" int orn_conv3x3_ps_silu_fwd_bf16(const float *x, const float *wf, const float *bf, int C, int O, int H, int W,
+                                            int s, float *z, float *a, void *ws, size_t ws_bytes, void *stream)
+{
+    ORN_REQUIRE(x && wf && bf && a && ws, "conv3x3_ps_silu_fwd_bf16: null pointer");
+    ORN_REQUIRE(C % CB_CK == 0 && O % 128 == 0 && O % (s * s) == 0, "conv3x3_ps_silu_fwd_bf16: unsupported C=%d O=%d s=%d", C, O, s);
+    if (ws_bytes < orn_conv3x3_ps_silu_bf16_ws_bytes(C, O, H, W, s)) { orn_set_error("conv3x3_ps_silu_fwd_bf16: workspace too small"); return ORN_E_WS; }
+    hipStream_t st = (hipStream_t)stream;
+    const Bf16Ws b = carve_bf16(ws, C, O, H, W, s);
+    const int Cn = O / (s * s), Hs = H * s, Ws = W * s;
+    ORN_TRY(orn_launch_nchw_to_nhwc_pad_bf16(x, C, H, W, b.xpad, st));
+    ORN_TRY(orn_launch_prep_weights_bf16(wf, bf, O, C, s, b.wb, b.wd, b.biasp, st));
+    ORN_TRY(orn_launch_conv_bf16_fwd(b.xpad, b.wb, b.biasp, H, W, C, O, s, b.zb, b.apad, st));
+    const long n = (long)Cn * Hs * Ws;
+    if (z) hipLaunchKernelGGL(k_nhwc_bf16_to_nchw_f32, dim3(orn_cdiv(n, 256)), dim3(256), 0, st, b.zb, Cn, Hs, Ws, 0, z);
+    hipLaunchKernelGGL(k_nhwc_bf16_to_nchw_f32, dim3(orn_cdiv(n, 256)), dim3(256), 0, st, b.apad, Cn, Hs, Ws, 1, a);
+    ORN_LAUNCH_CHECK("nhwc_bf16_to_nchw_f32");
+    return 0;
+}
+
+extern "C" int orn_conv3x3_ps_silu_bwd_bf16(const float *x, const float *wf, const float *z, const float *da, int C, int O,
+                                            int H, int W, int s, float *dx, float *dwf, float *dbf, void *ws,
+                                            size_t ws_bytes, void *stream)
+{
+    ORN_REQUIRE(x && wf && z && da && dwf && dbf && ws, "conv3x3_ps_silu_bwd_bf16: null pointer");
+    ORN_REQUIRE(C == 96 && O % 128 == 0 && O % (s * s) == 0, "conv3x3_ps_silu_bwd_bf16: unsupported C=%d O=%d", C, O);
+    if (ws_bytes < orn_conv3x3_ps_silu_bf16_ws_bytes(C, O, H, W, s)) { orn_set_error("conv3x3_ps_silu_bwd_bf16: workspace too small"); return ORN_E_WS; }
+    hipStream_t st = (hipStream_t)stream;
+    const Bf16Ws b = carve_bf16(ws, C, O, H, W, s);
+    const int Cn = O / (s * s);
+    ORN_TRY(orn_launch_nchw_to_nhwc_pad_bf16(x, C, H, W, b.xpad, st));
+    ORN_TRY(orn_launch_prep_weights_bf16(wf, dbf /*scratch: overwritten below*/, O, C, s, b.wb, b.wd, b.biasp, st));
+    const long n = (long)Cn * H * s * W * s;
+    hipLaunchKernelGGL(k_make_dy_bf16, dim3(orn_cdiv(n, 256)), dim3(256), 0, st, z, da, Cn, H, W, s, b.zb, b.dypad);
+    ORN_LAUNCH_CHECK("make_dy_bf16");
+    ORN_TRY(orn_launch_dbias_bf16(b.dypad, H, W, O, s, 1.0f, b.dbp, dbf, st));
+    ORN_TRY(orn_launch_wgrad_bf16(b.xpad, b.dypad, H, W, C, O, s, 1.0f, b.slabs, dwf, st));
+    if (dx) {
+        ORN_TRY(orn_launch_conv_bf16_dgrad(b.dypad, b.wd, H, W, O, C, nullptr, nullptr, 1, b.dxn, st));
+        ORN_TRY(orn_launch_nhwc_to_nchw_f32(b.dxn, C, H, W, dx, st));
+    }
+    return 0;
+}

@@ -80,6 +80,18 @@ int orn_conv3x3_ps_silu_bwd(const float *x, const float *wf, const float *z, con
                             int O, int H, int W, int s, float *dx, float *dwf, float *dbf, void *ws,
                             size_t ws_bytes, void *stream);
 
+/* ---- A4 on the bf16 MFMA path (fp32 accumulate): same contract as the two calls above for B = 1,
+ * C % 96 == 0 (bwd: C == 96), O % 128 == 0.  Inputs/outputs stay fp32 NCHW; the channels-last bf16
+ * staging (DESIGN.md "data layout") lives in `ws`, which the caller must zero-fill once before the
+ * first use (the one-pixel borders are never written).  The engine uses the same kernels without the
+ * layout conversions. */
+size_t orn_conv3x3_ps_silu_bf16_ws_bytes(int C, int O, int H, int W, int s);
+int orn_conv3x3_ps_silu_fwd_bf16(const float *x, const float *wf, const float *bf, int C, int O, int H, int W,
+                                 int s, float *z, float *a, void *ws, size_t ws_bytes, void *stream);
+int orn_conv3x3_ps_silu_bwd_bf16(const float *x, const float *wf, const float *z, const float *da, int C, int O,
+                                 int H, int W, int s, float *dx, float *dwf, float *dbf, void *ws,
+                                 size_t ws_bytes, void *stream);
+
 /* ---- A5  head: 1x1 conv -> (tanh+1)/2 or sigmoid                      model.py:621-622 --------
  * a [B,C,H,W]; w [3,C,1,1]; b [3]; out [B,3,H,W]. */
 int orn_head_fwd(const float *a, const float *w, const float *b, int B, int C, int H, int W, int sigmoid,
