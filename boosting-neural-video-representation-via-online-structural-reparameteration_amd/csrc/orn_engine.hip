@@ -8,8 +8,14 @@
 
 struct LayerBuf {
     float *T, *wf, *bf;   // merge products (ERB) -- wf/bf alias the params for vanilla/deploy
-    float *z, *a;         // block output (pre-activation, activation)
-    float *da;            // gradient wrt the block output
+    float *z, *a;         // block output (pre-activation, activation)          [fp32 layers]
+    float *da;            // gradient wrt the block output                       [fp32 layers]
+    // bf16 fast path (precision 1, layers >= ff): channels-last bf16, see orn_conv_bf16.hip
+    h16 *xpad;            // conv input, zero-bordered [H+2][W+2][C]
+    h16 *zb;              // pre-activation [Hs][Ws][Cn]
+    h16 *dypad;           // gradient wrt conv output, zero-bordered [H+2][W+2][O'] 
+    h16 *wb, *wd;         // merged kernel in bf16: forward / dgrad operand layouts
+    float *biasp;         // bias in o' order
 };
 
 struct orn_engine {
@@ -24,6 +30,8 @@ struct orn_engine {
     OrnStepCur *cur;                 // state of the step in flight (device)
     LayerBuf L[ORN_MAX_LAYERS];
     int Hout, Wout, Cn_last;
+    int ff;                          // first layer on the bf16 fast path (== n_layers: none)
+    float *dxn;                      // fp32 NHWC dgrad output of layer ff (converted to NCHW for the fp32 part)
     // graph cache (one captured train step)
     hipGraph_t graph;
     hipGraphExec_t graph_exec;
@@ -43,7 +51,7 @@ static int check_desc(const orn_engine_desc *d)
 {
     ORN_REQUIRE(d, "engine: null desc");
     ORN_REQUIRE(d->n_layers >= 1 && d->n_layers <= ORN_MAX_LAYERS, "engine: n_layers=%d out of range", d->n_layers);
-    ORN_REQUIRE(d->precision == 0, "engine: precision %d not built", d->precision);
+    ORN_REQUIRE(d->precision == 0 || d->precision == 1, "engine: precision %d not built", d->precision);
     ORN_REQUIRE(d->embed_len > 0 && d->stem_dim > 0 && d->fc_h > 0 && d->fc_w > 0 && d->fc_dim > 0, "engine: bad stem geometry");
     int C = d->fc_dim, H = d->fc_h, W = d->fc_w;
     for (int i = 0; i < d->n_layers; ++i) {
@@ -63,9 +71,28 @@ static int check_desc(const orn_engine_desc *d)
 }
 
 // Computes the workspace layout (in floats); if e != null also fills its pointers.
+static bool layer_is_fast(const orn_layer_desc &l)
+{
+    return l.C == 96 && l.O % 128 == 0 && l.O % (l.s * l.s) == 0;
+}
+
+// First layer from which every layer (and the head) can run on the bf16 MFMA path.
+static int first_fast_layer(const orn_engine_desc *d)
+{
+    if (d->precision != 1) return d->n_layers;
+    const orn_layer_desc &last = d->layer[d->n_layers - 1];
+    const int cn = last.O / (last.s * last.s);
+    if (!(cn == 32 || cn == 64 || cn == 96 || cn == 128)) return d->n_layers;
+    int ff = d->n_layers;
+    while (ff > 0 && layer_is_fast(d->layer[ff - 1])) --ff;
+    return ff;
+}
+
 static size_t layout(const orn_engine_desc *d, orn_engine *e)
 {
     size_t off = 0;
+    const int ff = first_fast_layer(d);
+    float *dxn = nullptr;
     float *base = e ? e->ws : nullptr;
     auto take = [&](size_t floats) { float *p = base ? base + off : nullptr; off += al(floats); return p; };
     const int Nout = d->fc_h * d->fc_w * d->fc_dim;
@@ -79,15 +106,28 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
         if (d->erb) { L[i].T = take(wsz); L[i].wf = take(wsz); L[i].bf = take(l.O); }
         Cn = l.O / (l.s * l.s); H = l.H * l.s; W = l.W * l.s;
         const size_t asz = (size_t)Cn * H * W;
-        L[i].z = take(asz); L[i].a = take(asz); L[i].da = take(asz);
-        size_t s1 = orn_conv3x3_ps_silu_bwd_ws_bytes(1, l.C, l.O, l.H, l.W) / 4;
+        size_t s1;
+        if (i < ff) {
+            L[i].z = take(asz); L[i].a = take(asz); L[i].da = take(asz);
+            s1 = orn_conv3x3_ps_silu_bwd_ws_bytes(1, l.C, l.O, l.H, l.W) / 4;
+        } else {
+            // halfs are carved as floats (2 per float)
+            L[i].xpad = (h16 *)take(((size_t)(l.H + 2) * (l.W + 2) * l.C + 1) / 2);
+            L[i].zb = (h16 *)take((asz + 1) / 2);
+            L[i].dypad = (h16 *)take(((size_t)(l.H + 2) * (l.W + 2) * l.O + 1) / 2);
+            L[i].wb = (h16 *)take((wsz + 1) / 2);
+            L[i].wd = (h16 *)take((wsz + 1) / 2);
+            L[i].biasp = take(l.O);
+            if (i == ff) dxn = take((size_t)l.H * l.W * l.C);
+            s1 = al(orn_wgrad_bf16_ws_floats(l.H, l.W, l.O)) + al(orn_dbias_bf16_ws_floats(l.H, l.O));
+        }
         if (d->erb) { const size_t s2 = orn_erb_merge_bwd_ws_bytes(l.C, l.O) / 4; if (s2 > s1) s1 = s2; }
         if (s1 > scratch) scratch = s1;
     }
     const size_t isz = (size_t)3 * H * W;
     float *img = take(isz), *dimg = take(isz), *stats = take(8);
     float *loss_ws = take(orn_loss_ws_bytes(1, 3, H, W) / 4);
-    const size_t s3 = orn_head_bwd_ws_bytes(1, Cn, H, W) / 4;
+    const size_t s3 = (ff < d->n_layers) ? orn_head_bwd_bf16_ws_floats(Cn) : orn_head_bwd_ws_bytes(1, Cn, H, W) / 4;
     if (s3 > scratch) scratch = s3;
     float *scr = take(scratch);
     float *cur = take(16);
@@ -97,6 +137,7 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
         e->cur = (OrnStepCur *)cur;
         for (int i = 0; i < d->n_layers; ++i) e->L[i] = L[i];
         e->Hout = H; e->Wout = W; e->Cn_last = Cn;
+        e->ff = ff; e->dxn = dxn;
     }
     return off * 4;
 }
@@ -127,6 +168,11 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
     e->ws = (float *)ws;
     e->graph = nullptr; e->graph_exec = nullptr;
     layout(d, e);
+    {   // the one-pixel borders of the channels-last buffers must be (and stay) zero
+        hipError_t rc = hipMemset(ws, 0, need);
+        if (rc == hipSuccess) rc = hipDeviceSynchronize();
+        if (rc != hipSuccess) { orn_set_error("engine_create: hipMemset failed: %s", hipGetErrorString(rc)); delete e; return (int)rc; }
+    }
     if (!d->erb)
         for (int i = 0; i < d->n_layers; ++i) {
             e->L[i].T = nullptr;
@@ -193,16 +239,28 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
                                    e->pre1, e->h1, st));
     ORN_TRY(orn_launch_linear_silu(e->h1, nullptr, 0, P + d.stem_w1, P + d.stem_b1, 1, d.stem_dim, Nout, e->pre2, e->h2, st));
     const float *x = e->h2;
-    for (int i = 0; i < d.n_layers; ++i) {
+    const int nl = d.n_layers, ff = e->ff;
+    for (int i = 0; i < nl; ++i) {
         const orn_layer_desc &l = d.layer[i];
         LayerBuf &b = e->L[i];
         if (d.erb)
             ORN_TRY(orn_launch_merge_fwd(P + l.w3x3, P + l.b3x3, P + l.w3x1, P + l.b3x1, P + l.w1x3, P + l.b1x3, P + l.w1,
                                          P + l.w2, P + l.w3, l.C, l.O, b.T, b.wf, b.bf, st));
-        ORN_TRY(orn_launch_conv3x3_f32(x, b.wf, b.bf, 1, l.C, l.O, l.H, l.W, l.s, 1, keep_z ? b.z : nullptr, b.a, st));
-        x = b.a;
+        if (i < ff) {
+            ORN_TRY(orn_launch_conv3x3_f32(x, b.wf, b.bf, 1, l.C, l.O, l.H, l.W, l.s, 1, keep_z ? b.z : nullptr, b.a, st));
+            x = b.a;
+        } else {
+            if (i == ff) ORN_TRY(orn_launch_nchw_to_nhwc_pad_bf16(x, l.C, l.H, l.W, b.xpad, st));
+            ORN_TRY(orn_launch_prep_weights_bf16(b.wf, b.bf, l.O, l.C, l.s, b.wb, b.wd, b.biasp, st));
+            ORN_TRY(orn_launch_conv_bf16_fwd(b.xpad, b.wb, b.biasp, l.H, l.W, l.C, l.O, l.s, b.zb,
+                                             (i + 1 < nl) ? e->L[i + 1].xpad : nullptr, st));
+        }
     }
-    ORN_TRY(orn_launch_head_fwd(x, P + d.head_w, P + d.head_b, 1, e->Cn_last, (size_t)e->Hout * e->Wout, d.sigmoid, e->img, st));
+    if (ff < nl)
+        ORN_TRY(orn_launch_head_fwd_bf16(e->L[nl - 1].zb, P + d.head_w, P + d.head_b, e->Cn_last, (size_t)e->Hout * e->Wout,
+                                         d.sigmoid, e->img, st));
+    else
+        ORN_TRY(orn_launch_head_fwd(x, P + d.head_w, P + d.head_b, 1, e->Cn_last, (size_t)e->Hout * e->Wout, d.sigmoid, e->img, st));
     return 0;
 }
 
@@ -233,15 +291,31 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         hipLaunchKernelGGL(k_publish_stats, dim3(1), dim3(64), 0, st, e->stats, e->cur, stats_out);
         ORN_LAUNCH_CHECK("publish_stats");
     }
-    const int nl = d.n_layers;
-    ORN_TRY(orn_launch_head_bwd(e->L[nl - 1].a, P + d.head_w, e->img, e->dimg, 1, e->Cn_last, HWo, d.sigmoid, e->L[nl - 1].da,
-                                G + d.head_w, G + d.head_b, e->scratch, st));
+    const int nl = d.n_layers, ff = e->ff;
+    if (ff < nl)
+        ORN_TRY(orn_launch_head_bwd_bf16(e->L[nl - 1].zb, P + d.head_w, e->img, e->dimg, e->Cn_last, e->Hout, e->Wout, d.sigmoid,
+                                         d.layer[nl - 1].s, 1.0f, e->L[nl - 1].dypad, G + d.head_w, G + d.head_b, e->scratch, st));
+    else
+        ORN_TRY(orn_launch_head_bwd(e->L[nl - 1].a, P + d.head_w, e->img, e->dimg, 1, e->Cn_last, HWo, d.sigmoid, e->L[nl - 1].da,
+                                    G + d.head_w, G + d.head_b, e->scratch, st));
     for (int i = nl - 1; i >= 0; --i) {
         const orn_layer_desc &l = d.layer[i];
         LayerBuf &b = e->L[i];
         const float *x = (i == 0) ? e->h2 : e->L[i - 1].a;
         float *dx = (i == 0) ? e->dh2 : e->L[i - 1].da;
         // dWf / dbf land directly in the 3x3 branch's gradient slots (dW3x3 = dWf, db3x3 = dbf)
+        if (i >= ff) {
+            float *slabs = e->scratch, *dbp = e->scratch + al(orn_wgrad_bf16_ws_floats(l.H, l.W, l.O));
+            ORN_TRY(orn_launch_dbias_bf16(b.dypad, l.H, l.W, l.O, l.s, 1.0f, dbp, G + l.b3x3, st));
+            ORN_TRY(orn_launch_wgrad_bf16(b.xpad, b.dypad, l.H, l.W, l.C, l.O, l.s, 1.0f, slabs, G + l.w3x3, st));
+            if (i > ff) {
+                ORN_TRY(orn_launch_conv_bf16_dgrad(b.dypad, b.wd, l.H, l.W, l.O, l.C, e->L[i - 1].zb, e->L[i - 1].dypad,
+                                                   d.layer[i - 1].s, nullptr, st));
+            } else {
+                ORN_TRY(orn_launch_conv_bf16_dgrad(b.dypad, b.wd, l.H, l.W, l.O, l.C, nullptr, nullptr, 1, e->dxn, st));
+                ORN_TRY(orn_launch_nhwc_to_nchw_f32(e->dxn, l.C, l.H, l.W, dx, st));
+            }
+        } else
         ORN_TRY(orn_launch_conv_bwd_f32(x, b.wf, b.z, b.da, 1, l.C, l.O, l.H, l.W, l.s, dx, G + l.w3x3, G + l.b3x3, e->scratch, st));
         if (d.erb)
             ORN_TRY(orn_launch_merge_bwd(G + l.w3x3, G + l.b3x3, P + l.w1, P + l.w2, P + l.w3, b.T, l.C, l.O, G + l.w3x3,

@@ -35,3 +35,23 @@ int orn_loss_init();
 int orn_launch_loss(const float *pred, const float *target, const int *frame_idx, size_t frame_stride, int B, int Ch,
                     int H, int W, int loss_type, float loss_scale, float *stats, float *dpred, float *ws,
                     hipStream_t st);
+
+// orn_conv_bf16.hip (bf16 MFMA fast path; channels-last bf16 buffers, see file header)
+typedef __bf16 h16;
+int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p, int H, int W, int Cin, int O, int s,
+                             h16 *z, h16 *apad, hipStream_t st);
+int orn_launch_conv_bf16_dgrad(const h16 *dypad, const h16 *wd, int H, int W, int O, int C, const h16 *zprev,
+                               h16 *dyprev, int sp, float *dx_f32, hipStream_t st);
+size_t orn_wgrad_bf16_ws_floats(int H, int W, int O);
+int orn_launch_wgrad_bf16(const h16 *xpad, const h16 *dypad, int H, int W, int C, int O, int s, float gscale,
+                          float *slabs, float *dwf, hipStream_t st);
+int orn_launch_prep_weights_bf16(const float *wf, const float *bf, int O, int C, int s, h16 *wb, h16 *wd, float *bias_p,
+                                 hipStream_t st);
+int orn_launch_nchw_to_nhwc_pad_bf16(const float *src, int C, int H, int W, h16 *dst, hipStream_t st);
+int orn_launch_nhwc_to_nchw_f32(const float *src, int C, int H, int W, float *dst, hipStream_t st);
+size_t orn_dbias_bf16_ws_floats(int H, int O);
+int orn_launch_dbias_bf16(const h16 *dypad, int H, int W, int O, int s, float gscale, float *partial, float *dbf, hipStream_t st);
+int orn_launch_head_fwd_bf16(const h16 *z, const float *w, const float *b, int C, size_t HW, int sigmoid, float *out, hipStream_t st);
+size_t orn_head_bwd_bf16_ws_floats(int C);
+int orn_launch_head_bwd_bf16(const h16 *z, const float *w, const float *out, const float *dout, int C, int H, int W, int sigmoid,
+                             int sp, float gscale, h16 *dypad, float *dw, float *db, float *ws, hipStream_t st);

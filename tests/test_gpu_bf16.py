@@ -70,3 +70,70 @@ def test_bf16_block_fwd_bwd(orn, C, O, H, W, s):
     np.testing.assert_allclose(dwf.cpu().numpy(), gw.numpy(), rtol=2e-3, atol=2e-3 * sc)
     np.testing.assert_allclose(dbf.cpu().numpy(), gb.numpy(), rtol=2e-3, atol=2e-3 * float(gb.abs().max()))
     np.testing.assert_allclose(dx.cpu().numpy(), gx.numpy(), rtol=2e-3, atol=2e-3 * float(gx.abs().max()))
+
+
+def _mk(orn, fc, strides, lower_width, bt='ERB'):
+    torch.manual_seed(1)
+    return orn.model.Generator(embed_length=80, stem_dim_num='32_1', fc_hw_dim=fc, expansion=1, num_blocks=1, norm='none',
+                               act='swish', bias=True, reduction=2, conv_type='conv', stride_list=strides, sin_res=True,
+                               lower_width=lower_width, sigmoid=False, deploy=False, branch_type=bt)
+
+
+def _rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize('fc,strides,lw,bt', [('3_4_96', [2, 2], 96, 'ERB'), ('2_3_26', [5, 2, 2], 96, 'ERB'),
+                                               ('3_4_96', [2, 2, 2], 96, 'NeRV_vanilla')])
+def test_bf16_engine_vs_fp32_engine(orn, fc, strides, lw, bt):
+    """One optimiser step of the bf16 engine vs the fp32 engine (itself pinned to the oracle):
+    same loss to 2e-3 relative, every gradient tensor within 3 % relative L2 (bf16 activations /
+    weights, fp32 accumulation), decode output within 2e-2 abs."""
+    from oracle import cpu_ref
+    res = {}
+    n_frames = 3
+    hw = None
+    for prec in ('fp32', 'bf16'):
+        gen = _mk(orn, fc, strides, lw, bt)
+        eng = orn.engine.TrainEngine(gen, loss_type='Fusion6', beta=0.5, precision=prec)
+        if hw is None:
+            hw = eng.out_hw
+            frames = cpu_ref.synthetic_video(n_frames, hw[0], hw[1], seed=5)
+            embeds = cpu_ref.positional_encoding(torch.tensor([k / n_frames for k in range(n_frames)]), 1.25, 40)
+        eng.set_video(frames, embeds)
+        eng.set_schedule([(1, 1, 0.0)])          # lr 0: parameters stay put, gradients are what we compare
+        eng.run(1, graph=(prec == 'bf16'))
+        torch.cuda.synchronize()
+        grads = {k: eng.grads[off:off + n].clone().cpu() for k, (off, n) in eng.layout.items()}
+        img = eng.decode(embeds[2]).cpu()
+        res[prec] = (eng.stats(1)[0].clone(), grads, img)
+    sf, gf, imf = res['fp32']
+    sb, gb, imb = res['bf16']
+    assert abs(sb[0] - sf[0]) <= 2e-3 * abs(sf[0]), (sb, sf)
+    assert abs(sb[4] - sf[4]) <= 0.05, (sb, sf)                   # PSNR of the prediction, dB
+    assert torch.max(torch.abs(imb - imf)) < 2e-2
+    worst = max((_rel(gb[k], gf[k]), k) for k in gf if gf[k].norm() > 0)
+    assert worst[0] < 3e-2, worst
+
+
+def test_bf16_engine_720p_decode_and_step(orn):
+    """BASELINE config 2 on the bf16 path: decode agrees with the fp32 path (PSNR between the two
+    decoders > 50 dB) and a training step runs with finite loss and gradients close to fp32."""
+    import bench
+    outs = {}
+    for prec in ('fp32', 'bf16'):
+        eng = bench.make_engine(seed=1234, precision=prec)
+        eng.set_schedule([(7, 1, 0.0)])
+        eng.run(1, graph=True)
+        torch.cuda.synchronize()
+        outs[prec] = (eng.decode(eng.embeds[7]).cpu(), eng.stats(1)[0].clone(),
+                      {k: eng.grads[off:off + n].clone().cpu() for k, (off, n) in eng.layout.items()})
+        del eng
+        torch.cuda.empty_cache()
+    imf, sf, gf = outs['fp32']
+    imb, sb, gb = outs['bf16']
+    mse = float(((imf - imb) ** 2).mean())
+    assert -10 * math.log10(mse) > 50.0, mse
+    assert torch.isfinite(sb).all() and abs(sb[0] - sf[0]) <= 2e-3 * abs(sf[0])
+    worst = max((_rel(gb[k], gf[k]), k) for k in gf if gf[k].norm() > 0)
+    assert worst[0] < 5e-2, worst
