@@ -267,6 +267,7 @@ struct WgradBP {
     const h16 *xpad;    // [H+2][W+2][96]
     const h16 *dypad;   // [H+2][W+2][O]
     float *slabs;       // [S][9][O][96]
+    float *bias_slabs;  // [S][O]  (column sums of dy, from the ti == 1 work-groups)
     int H, W, O;
     int tiles_w, n_ktiles, S, n_otiles;
 };
@@ -306,6 +307,14 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p)
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][c][r] = 0.f;
+    // dbias rides along in the ti == 1 work-groups: dy^T x ones on the matrix core (wave-uniform branch)
+    f32x16 accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+    h16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (h16)1.0f;
+    const bool do_bias = (ti == 1);
 
     // per-lane transposed-read offsets (pixel part is added per K slice)
     const int a_off = (8 * (g >> 1) + lq) * WB_DYB + (wave * 32 + 16 * (g & 1) + 4 * lp) * 2;
@@ -338,6 +347,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p)
             for (int half = 0; half < 2; ++half) {
                 const unsigned char *ap = dys + (r * WB_TW + 16 * half) * WB_DYB + a_off;
                 const h16x8 a = tr_frag(ap, ap + 4 * WB_DYB);
+                if (do_bias) accb = MFMA_H16(a, ones, accb);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const unsigned char *bp = xs + (r * WB_XW + 16 * half + j) * WB_XB + b_off;
@@ -348,6 +358,11 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p)
                     }
                 }
             }
+    }
+    if (do_bias && l31 == 0) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            p.bias_slabs[(size_t)sidx * O + o0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh] = accb[reg];
     }
     float *out = p.slabs + (size_t)sidx * 9 * O * 96;
 #pragma unroll
@@ -362,11 +377,17 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p)
 }
 
 // dWf[o][c][i][j] = gscale * sum_s slabs[s][tap][o'(o)][c],  o' = (o % s2)*Cn + o / s2
-__global__ void k_wgrad_bf16_reduce(const float *__restrict__ slabs, int S, int O, int Cn, int s2, float gscale,
-                                    float *__restrict__ dwf)
+__global__ void k_wgrad_bf16_reduce(const float *__restrict__ slabs, const float *__restrict__ bias_slabs, int S, int O, int Cn,
+                                    int s2, float gscale, float *__restrict__ dwf, float *__restrict__ dbf)
 {
     const size_t n = (size_t)9 * O * 96;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (size_t)O && dbf) {
+        float b = 0.f;
+        for (int s = 0; s < S; ++s) b += bias_slabs[(size_t)s * O + idx];
+        const int ij = (int)idx / Cn, nn = (int)idx - ij * Cn;
+        dbf[nn * s2 + ij] = b * gscale;
+    }
     if (idx >= n) return;
     float acc = 0.f;
     for (int s = 0; s < S; ++s) acc += slabs[(size_t)s * n + idx];
@@ -388,10 +409,11 @@ int orn_wgrad_bf16_split(int H, int W, int O)
     return S;
 }
 
-size_t orn_wgrad_bf16_ws_floats(int H, int W, int O) { return (size_t)orn_wgrad_bf16_split(H, W, O) * 9 * O * 96; }
+size_t orn_wgrad_bf16_ws_floats(int H, int W, int O) { return (size_t)orn_wgrad_bf16_split(H, W, O) * (9 * (size_t)O * 96 + O); }
 
+// dwf [O][96][3][3] and dbf [O] (PyTorch channel order), both overwritten.
 int orn_launch_wgrad_bf16(const h16 *xpad, const h16 *dypad, int H, int W, int C, int O, int s, float gscale,
-                          float *slabs, float *dwf, hipStream_t st)
+                          float *slabs, float *dwf, float *dbf, hipStream_t st)
 {
     ORN_REQUIRE(C == 96 && O % WB_BO == 0 && O % (s * s) == 0, "wgrad_bf16: unsupported C=%d O=%d", C, O);
     WgradBP p;
@@ -399,6 +421,7 @@ int orn_launch_wgrad_bf16(const h16 *xpad, const h16 *dypad, int H, int W, int C
     p.tiles_w = orn_cdiv(W, WB_TW);
     p.n_ktiles = p.tiles_w * orn_cdiv(H, WB_TH);
     p.S = orn_wgrad_bf16_split(H, W, O);
+    p.bias_slabs = slabs + (size_t)p.S * 9 * O * 96;
     p.n_otiles = O / WB_BO;
     static bool attr_done = false;
     const size_t smem = WB_DY_BYTES + WB_X_BYTES;
@@ -410,8 +433,8 @@ int orn_launch_wgrad_bf16(const h16 *xpad, const h16 *dypad, int H, int W, int C
     hipLaunchKernelGGL(k_wgrad_nhwc_bf16, dim3(3 * p.n_otiles * p.S), dim3(256), smem, st, p);
     ORN_LAUNCH_CHECK("wgrad_nhwc_bf16");
     const size_t n = (size_t)9 * O * 96;
-    hipLaunchKernelGGL(k_wgrad_bf16_reduce, dim3(orn_cdiv((long)n, 256)), dim3(256), 0, st, slabs, p.S, O, O / (s * s), s * s,
-                       gscale, dwf);
+    hipLaunchKernelGGL(k_wgrad_bf16_reduce, dim3(orn_cdiv((long)n, 256)), dim3(256), 0, st, slabs, p.bias_slabs, p.S, O,
+                       O / (s * s), s * s, gscale, dwf, dbf);
     ORN_LAUNCH_CHECK("wgrad_bf16_reduce");
     return 0;
 }
@@ -669,7 +692,7 @@ __global__ void k_head_bf16_finish(const float *__restrict__ red, int C, float g
     else if (i < 3 * C + 3) db[i - 3 * C] = red[i] * gscale;
 }
 
-#define HB_BLOCKS 1024
+#define HB_BLOCKS 256
 
 int orn_launch_head_fwd_bf16(const h16 *z, const float *w, const float *b, int C, size_t HW, int sigmoid, float *out, hipStream_t st)
 {
@@ -816,8 +839,7 @@ extern "C" int orn_conv3x3_ps_silu_bwd_bf16(const float *x, const float *wf, con
     const long n = (long)Cn * H * s * W * s;
     hipLaunchKernelGGL(k_make_dy_bf16, dim3(orn_cdiv(n, 256)), dim3(256), 0, st, z, da, Cn, H, W, s, b.zb, b.dypad);
     ORN_LAUNCH_CHECK("make_dy_bf16");
-    ORN_TRY(orn_launch_dbias_bf16(b.dypad, H, W, O, s, 1.0f, b.dbp, dbf, st));
-    ORN_TRY(orn_launch_wgrad_bf16(b.xpad, b.dypad, H, W, C, O, s, 1.0f, b.slabs, dwf, st));
+    ORN_TRY(orn_launch_wgrad_bf16(b.xpad, b.dypad, H, W, C, O, s, 1.0f, b.slabs, dwf, dbf, st));
     if (dx) {
         ORN_TRY(orn_launch_conv_bf16_dgrad(b.dypad, b.wd, H, W, O, C, nullptr, nullptr, 1, b.dxn, st));
         ORN_TRY(orn_launch_nhwc_to_nchw_f32(b.dxn, C, H, W, dx, st));

@@ -36,6 +36,7 @@ struct ConvP {
     float *z;           // EPI_PS_SILU: pre-activation (may be null)
     int B, C, O, H, W, s;
     int tiles_w, tiles_h;
+    int nsplit, c_per_split;   // EPI_PLAIN: input channels split over blockIdx.z (partial slabs, reduced afterwards)
 };
 
 template <int EPI>
@@ -50,9 +51,10 @@ __global__ void __launch_bounds__(256) k_conv3x3_f32(ConvP p)
     const int tw = tile % p.tiles_w, th = tile / p.tiles_w;
     const int h0 = th * CV_TH, w0 = tw * CV_TW;
     const int o0 = blockIdx.y * CV_BO;
-    const int b = blockIdx.z;
+    const int b = blockIdx.z / p.nsplit, split = blockIdx.z - b * p.nsplit;
     const int C = p.C, H = p.H, W = p.W;
     const float *xb = p.x + (size_t)b * C * H * W;
+    const int c_begin = split * p.c_per_split, c_end = min(C, c_begin + p.c_per_split);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -63,7 +65,7 @@ __global__ void __launch_bounds__(256) k_conv3x3_f32(ConvP p)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int r0 = wave * 2;                   // first of the wave's two output rows (tile-local)
-    for (int c0 = 0; c0 < C; c0 += CV_CC) {
+    for (int c0 = c_begin; c0 < c_end; c0 += CV_CC) {
         // ---- stage the input patch (zero padded) and the weight tile --------------------------
         for (int idx = t; idx < CV_CC * CV_XH * CV_XW; idx += 256) {
             const int c = idx / (CV_XH * CV_XW);
@@ -71,13 +73,13 @@ __global__ void __launch_bounds__(256) k_conv3x3_f32(ConvP p)
             const int r = rem / CV_XW, xx = rem - r * CV_XW;
             const int gh = h0 + r - 1, gw = w0 + xx - 1, gc = c0 + c;
             float v = 0.f;
-            if (gc < C && gh >= 0 && gh < H && gw >= 0 && gw < W) v = xb[((size_t)gc * H + gh) * W + gw];
+            if (gc < c_end && gh >= 0 && gh < H && gw >= 0 && gw < W) v = xb[((size_t)gc * H + gh) * W + gw];
             (&Xs[0][0][0])[idx] = v;
         }
         for (int idx = t; idx < CV_BO * CV_CC * 9; idx += 256) {
             const int o = idx / (CV_CC * 9), kk = idx - o * (CV_CC * 9);
             float v = 0.f;
-            if (o0 + o < p.O && c0 * 9 + kk < C * 9) v = p.w[(size_t)(o0 + o) * C * 9 + (size_t)c0 * 9 + kk];
+            if (o0 + o < p.O && c0 * 9 + kk < c_end * 9) v = p.w[(size_t)(o0 + o) * C * 9 + (size_t)c0 * 9 + kk];
             Ws[o][kk] = v;
         }
         __syncthreads();
@@ -121,7 +123,7 @@ __global__ void __launch_bounds__(256) k_conv3x3_f32(ConvP p)
                 float v = acc[ob][rr][reg];
                 if (p.bias) v += p.bias[o];
                 if (EPI == EPI_PLAIN) {
-                    p.out[(((size_t)b * p.O + o) * H + gh) * W + gw] = v;
+                    p.out[((((size_t)split * p.B + b) * p.O + o) * H + gh) * W + gw] = v;
                 } else {
                     const int s = p.s, ss = s * s;
                     const int n = o / ss, rem = o - n * ss, si = rem / s, sj = rem - si * s;
@@ -134,14 +136,38 @@ __global__ void __launch_bounds__(256) k_conv3x3_f32(ConvP p)
         }
 }
 
+// Small images leave most CUs idle: split the input channels over work-groups (plain epilogue only).
+int orn_conv3x3_f32_nsplit(int B, int C, int O, int H, int W)
+{
+    const long wgs = (long)orn_cdiv(W, CV_TW) * orn_cdiv(H, CV_TH) * orn_cdiv(O, CV_BO) * B;
+    int ns = (int)(512 / (wgs > 0 ? wgs : 1));
+    const int maxs = orn_cdiv(C, 2 * CV_CC);
+    if (ns > maxs) ns = maxs;
+    return ns < 1 ? 1 : ns;
+}
+
 int orn_launch_conv3x3_f32(const float *x, const float *w, const float *bias, int B, int C, int O, int H, int W,
-                           int s, int epi, float *z, float *out, hipStream_t st)
+                           int s, int epi, float *z, float *out, hipStream_t st, float *split_ws)
 {
     ConvP p;
     p.x = x; p.w = w; p.bias = bias; p.out = out; p.z = z;
     p.B = B; p.C = C; p.O = O; p.H = H; p.W = W; p.s = s;
     p.tiles_w = orn_cdiv(W, CV_TW);
     p.tiles_h = orn_cdiv(H, CV_TH);
+    p.nsplit = 1; p.c_per_split = C;
+    if (epi == EPI_PLAIN && split_ws && !bias) {
+        const int ns = orn_conv3x3_f32_nsplit(B, C, O, H, W);
+        if (ns > 1) {
+            p.c_per_split = orn_cdiv(orn_cdiv(C, ns), CV_CC) * CV_CC;
+            p.nsplit = orn_cdiv(C, p.c_per_split);
+            p.out = split_ws;
+            dim3 grid(p.tiles_w * p.tiles_h, orn_cdiv(O, CV_BO), B * p.nsplit);
+            hipLaunchKernelGGL(k_conv3x3_f32<EPI_PLAIN>, grid, dim3(256), 0, st, p);
+            ORN_LAUNCH_CHECK("conv3x3_f32(split)");
+            const size_t n = (size_t)B * O * H * W;
+            return orn_launch_reduce_rows(split_ws, p.nsplit, n, n, out, st);
+        }
+    }
     dim3 grid(p.tiles_w * p.tiles_h, orn_cdiv(O, CV_BO), B);
     if (epi == EPI_PS_SILU) hipLaunchKernelGGL(k_conv3x3_f32<EPI_PS_SILU>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(k_conv3x3_f32<EPI_PLAIN>, grid, dim3(256), 0, st, p);
@@ -155,7 +181,7 @@ extern "C" int orn_conv3x3_ps_silu_fwd(const float *x, const float *wf, const fl
     ORN_REQUIRE(x && wf && a, "conv3x3_ps_silu_fwd: null pointer");
     ORN_REQUIRE(B > 0 && C > 0 && O > 0 && H > 0 && W > 0 && s > 0, "conv3x3_ps_silu_fwd: bad sizes");
     ORN_REQUIRE(O % (s * s) == 0, "conv3x3_ps_silu_fwd: O=%d not divisible by s*s=%d", O, s * s);
-    return orn_launch_conv3x3_f32(x, wf, bf, B, C, O, H, W, s, EPI_PS_SILU, z, a, (hipStream_t)stream);
+    return orn_launch_conv3x3_f32(x, wf, bf, B, C, O, H, W, s, EPI_PS_SILU, z, a, (hipStream_t)stream, nullptr);
 }
 
 // ================================================================================================
@@ -332,6 +358,7 @@ extern "C" size_t orn_conv3x3_ps_silu_bwd_ws_bytes(int B, int C, int O, int H, i
     f += orn_align((size_t)O * C * 9 * 4) / 4;                          // Wd
     f += orn_align((size_t)wgrad_split(B, C, O, H, W) * O * C * 9 * 4) / 4;   // wgrad partial slabs
     f += orn_align((size_t)B * chunks * O * 4) / 4;                     // dbias partials
+    f += orn_align((size_t)orn_conv3x3_f32_nsplit(B, O, C, H, W) * B * C * HW * 4) / 4;   // dgrad channel-split slabs
     return f * 4;
 }
 
@@ -345,6 +372,7 @@ int orn_launch_conv_bwd_f32(const float *x, const float *wf, const float *z, con
     float *wd = dy + orn_align((size_t)B * O * HW * 4) / 4;
     float *slabs = wd + orn_align((size_t)O * C * 9 * 4) / 4;
     float *dbp = slabs + orn_align((size_t)S * O * C * 9 * 4) / 4;
+    float *dgs = dbp + orn_align((size_t)B * chunks * O * 4) / 4;
 
     hipLaunchKernelGGL(k_silu_bwd_unshuffle, dim3(chunks, O, B), dim3(256), 0, st, da, z, O, H, W, s, dy, dbp);
     ORN_LAUNCH_CHECK("silu_bwd_unshuffle");
@@ -364,7 +392,7 @@ int orn_launch_conv_bwd_f32(const float *x, const float *wf, const float *z, con
     if (dx) {
         hipLaunchKernelGGL(k_flip_transpose_w, dim3(orn_cdiv((long)O * C * 9, 256)), dim3(256), 0, st, wf, O, C, wd);
         ORN_LAUNCH_CHECK("flip_transpose_w");
-        ORN_TRY(orn_launch_conv3x3_f32(dy, wd, nullptr, B, O, C, H, W, 1, EPI_PLAIN, nullptr, dx, st));
+        ORN_TRY(orn_launch_conv3x3_f32(dy, wd, nullptr, B, O, C, H, W, 1, EPI_PLAIN, nullptr, dx, st, dgs));
     }
     return 0;
 }

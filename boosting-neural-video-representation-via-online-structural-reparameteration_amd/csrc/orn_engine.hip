@@ -247,7 +247,7 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
             ORN_TRY(orn_launch_merge_fwd(P + l.w3x3, P + l.b3x3, P + l.w3x1, P + l.b3x1, P + l.w1x3, P + l.b1x3, P + l.w1,
                                          P + l.w2, P + l.w3, l.C, l.O, b.T, b.wf, b.bf, st));
         if (i < ff) {
-            ORN_TRY(orn_launch_conv3x3_f32(x, b.wf, b.bf, 1, l.C, l.O, l.H, l.W, l.s, 1, keep_z ? b.z : nullptr, b.a, st));
+            ORN_TRY(orn_launch_conv3x3_f32(x, b.wf, b.bf, 1, l.C, l.O, l.H, l.W, l.s, 1, keep_z ? b.z : nullptr, b.a, st, nullptr));
             x = b.a;
         } else {
             if (i == ff) ORN_TRY(orn_launch_nchw_to_nhwc_pad_bf16(x, l.C, l.H, l.W, b.xpad, st));
@@ -305,9 +305,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         float *dx = (i == 0) ? e->dh2 : e->L[i - 1].da;
         // dWf / dbf land directly in the 3x3 branch's gradient slots (dW3x3 = dWf, db3x3 = dbf)
         if (i >= ff) {
-            float *slabs = e->scratch, *dbp = e->scratch + al(orn_wgrad_bf16_ws_floats(l.H, l.W, l.O));
-            ORN_TRY(orn_launch_dbias_bf16(b.dypad, l.H, l.W, l.O, l.s, 1.0f, dbp, G + l.b3x3, st));
-            ORN_TRY(orn_launch_wgrad_bf16(b.xpad, b.dypad, l.H, l.W, l.C, l.O, l.s, 1.0f, slabs, G + l.w3x3, st));
+            ORN_TRY(orn_launch_wgrad_bf16(b.xpad, b.dypad, l.H, l.W, l.C, l.O, l.s, 1.0f, e->scratch, G + l.w3x3, G + l.b3x3, st));
             if (i > ff) {
                 ORN_TRY(orn_launch_conv_bf16_dgrad(b.dypad, b.wd, l.H, l.W, l.O, l.C, e->L[i - 1].zb, e->L[i - 1].dypad,
                                                    d.layer[i - 1].s, nullptr, st));

@@ -26,7 +26,7 @@ int orn_launch_merge_bwd(const float *g, const float *dbf, const float *w1, cons
 
 // orn_conv_f32.hip
 int orn_launch_conv3x3_f32(const float *x, const float *w, const float *bias, int B, int C, int O, int H, int W,
-                           int s, int epi, float *z, float *out, hipStream_t st);
+                           int s, int epi, float *z, float *out, hipStream_t st, float *split_ws);
 int orn_launch_conv_bwd_f32(const float *x, const float *wf, const float *z, const float *da, int B, int C, int O,
                             int H, int W, int s, float *dx, float *dwf, float *dbf, float *ws, hipStream_t st);
 
@@ -44,7 +44,7 @@ int orn_launch_conv_bf16_dgrad(const h16 *dypad, const h16 *wd, int H, int W, in
                                h16 *dyprev, int sp, float *dx_f32, hipStream_t st);
 size_t orn_wgrad_bf16_ws_floats(int H, int W, int O);
 int orn_launch_wgrad_bf16(const h16 *xpad, const h16 *dypad, int H, int W, int C, int O, int s, float gscale,
-                          float *slabs, float *dwf, hipStream_t st);
+                          float *slabs, float *dwf, float *dbf, hipStream_t st);
 int orn_launch_prep_weights_bf16(const float *wf, const float *bf, int O, int C, int s, h16 *wb, h16 *wd, float *bias_p,
                                  hipStream_t st);
 int orn_launch_nchw_to_nhwc_pad_bf16(const float *src, int C, int H, int W, h16 *dst, hipStream_t st);

@@ -21,72 +21,93 @@ struct GemmP {
     int Cch;
 };
 
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// 64x64 output tile per work-group, 4 waves (2x2), each wave one 32x32 v_mfma_f32_32x32x2_f32 block.
+// K is consumed in ascending order, 2 per instruction (lane half 0 = even k first, then odd k), the
+// 32-deep chunks in ascending order, always into the same accumulator: one k-ordered fmaf chain per
+// output element, bit-identical to oracle/merge_ref.c.  Out-of-range K is zero-filled
+// (fma(0, 0, acc) == acc).  Next chunk's global loads are issued before the MFMAs of the current one.
 #define GT 64
-#define GK 16
-#define GLD (GT + 4)
+#define GK 32
+#define GLDA (GK + 1)
+#define GLDB (GT + 4)
 
 __global__ void __launch_bounds__(256) k_gemm_f32(GemmP p)
 {
-    __shared__ __attribute__((aligned(16))) float As[GK][GLD];
-    __shared__ __attribute__((aligned(16))) float Bs[GK][GLD];
-    const int t = threadIdx.x;
+    __shared__ float As[2][GT][GLDA];
+    __shared__ float Bs[2][GK][GLDB];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
     const float *A = p.A + (long)blockIdx.z * p.ba;
     const float *B = p.B + (long)blockIdx.z * p.bb;
     float *C = p.C + (long)blockIdx.z * p.bc;
-    const int tx = t & 15, ty = t >> 4;
-    float acc[4][4];
+    f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    for (int k0 = 0; k0 < p.K; k0 += GK) {
+    float ra[8], rb[8];
+    auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
             int kk, m;
-            if (p.a_kfast) { kk = t & 15; m = (t >> 4) + 16 * i; }
+            if (p.a_kfast) { kk = t & 31; m = (t >> 5) + 8 * i; }
             else           { m = t & 63;  kk = (t >> 6) + 4 * i; }
             const int gm = m0 + m, gk = k0 + kk;
-            As[kk][m] = (gm < p.M && gk < p.K) ? A[(long)gm * p.sam + (long)gk * p.sak] : 0.f;
+            ra[i] = (gm < p.M && gk < p.K) ? A[(long)gm * p.sam + (long)gk * p.sak] : 0.f;
             int kb, n;
             if (p.b_nfast) { n = t & 63;  kb = (t >> 6) + 4 * i; }
-            else           { kb = t & 15; n = (t >> 4) + 16 * i; }
+            else           { kb = t & 31; n = (t >> 5) + 8 * i; }
             const int gn = n0 + n, gkb = k0 + kb;
-            Bs[kb][n] = (gn < p.N && gkb < p.K) ? B[(long)gkb * p.sbk + (long)gn * p.sbn] : 0.f;
+            rb[i] = (gn < p.N && gkb < p.K) ? B[(long)gkb * p.sbk + (long)gn * p.sbn] : 0.f;
         }
-        __syncthreads();
+    };
+    auto lstore = [&](int buf) {
 #pragma unroll
-        for (int kk = 0; kk < GK; ++kk) {
-            const float4 a4 = *reinterpret_cast<const float4 *>(&As[kk][ty * 4]);
-            const float4 b4 = *reinterpret_cast<const float4 *>(&Bs[kk][tx * 4]);
-            const float a[4] = {a4.x, a4.y, a4.z, a4.w};
-            const float b[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        for (int i = 0; i < 8; ++i) {
+            int kk, m;
+            if (p.a_kfast) { kk = t & 31; m = (t >> 5) + 8 * i; }
+            else           { m = t & 63;  kk = (t >> 6) + 4 * i; }
+            As[buf][m][kk] = ra[i];
+            int kb, n;
+            if (p.b_nfast) { n = t & 63;  kb = (t >> 6) + 4 * i; }
+            else           { kb = t & 31; n = (t >> 5) + 8 * i; }
+            Bs[buf][kb][n] = rb[i];
         }
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < p.K; k0 += GK) {
+        const bool has_next = (k0 + GK < p.K);
+        if (has_next) gload(k0 + GK);
+        const float *ap = &As[cur][wm * 32 + l31][hh];
+        const float *bp = &Bs[cur][hh][wn * 32 + l31];
+#pragma unroll
+        for (int kk = 0; kk < GK; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk * GLDB], acc, 0, 0, 0);
+        if (has_next) lstore(cur ^ 1);
         __syncthreads();
+        cur ^= 1;
     }
+    const int gn = n0 + wn * 32 + l31;
+    if (gn >= p.N) return;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gm = m0 + ty * 4 + i;
+    for (int reg = 0; reg < 16; ++reg) {
+        const int gm = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
         if (gm >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int gn = n0 + tx * 4 + j;
-            if (gn >= p.N) continue;
-            float r = acc[i][j];
-            if (p.epi == 1) {
-                const int c = gn / 9, ij = gn % 9, ii = ij / 3, jj = ij % 3;
-                const long oc = (long)gm * p.Cch + c;
-                const float p13 = (ii == 1) ? p.w1x3[oc * 3 + jj] : 0.f;
-                const float p31 = (jj == 1) ? p.w3x1[oc * 3 + ii] : 0.f;
-                r = (p.w3x3[(long)gm * p.N + gn] + (p13 + p31)) + r;   // association of model.py:475,495
-            }
-            C[(long)gm * p.scm + (long)gn * p.scn] = r;
+        float r = acc[reg];
+        if (p.epi == 1) {
+            const int c = gn / 9, ij = gn % 9, ii = ij / 3, jj = ij % 3;
+            const long oc = (long)gm * p.Cch + c;
+            const float p13 = (ii == 1) ? p.w1x3[oc * 3 + jj] : 0.f;
+            const float p31 = (jj == 1) ? p.w3x1[oc * 3 + ii] : 0.f;
+            r = (p.w3x3[(long)gm * p.N + gn] + (p13 + p31)) + r;   // association of model.py:475,495
         }
+        C[(long)gm * p.scm + (long)gn * p.scn] = r;
     }
 }
 
