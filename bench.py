@@ -74,28 +74,47 @@ def schedule(n_steps, start_step=0):
 
 
 def conv_roofline(eng, precision, iters=10):
-    """Dominant kernel = the implicit-GEMM 3x3 conv forward (5 launches/step: L0..L4).  Times every
-    launch of that kernel symbol in a step with HIP events on the launch stream and returns
-    (algorithmic flops per launch, avg launch duration [s]) averaged over the 5 launches so that it
-    agrees with rocprofv3's per-kernel average."""
+    """Dominant kernel = the implicit-GEMM 3x3 conv forward.  fp32: k_conv3x3_f32<EPI_PS_SILU>, 5 launches
+    per step (L0..L4); bf16: k_conv_nhwc_bf16<4,2,2,2,EPI_B_FWD>, 3 launches per step (L2..L4).  Times
+    every launch of that kernel symbol in a step with HIP events on the launch stream and returns
+    (algorithmic flops per launch, avg launch duration [s]) averaged over those launches, so that it
+    agrees with rocprofv3's per-kernel average for the symbol."""
     from orn_amd import _lib
+    from ctypes import c_void_p
     lib = _lib.lib()
     geo = layer_geo()
     dev = eng.device
     tot_t, tot_f, n = 0.0, 0.0, 0
     per_layer = []
-    for L in geo:
+    for li, L in enumerate(geo):
         C, O, s, H, W = L['C'], L['O'], L['s'], L['H'], L['W']
-        x = torch.randn(1, C, H, W, device=dev)
-        wf = torch.randn(O, C, 3, 3, device=dev) * (1.0 / (9 * C) ** 0.5)
-        bf = torch.zeros(O, device=dev)
-        z = torch.empty(1, O // (s * s), H * s, W * s, device=dev)
-        a = torch.empty_like(z)
         st = _lib.stream()
+        if precision == 'bf16':
+            if C != 96:
+                continue
+            Cn = O // (s * s)
+            xpad = torch.zeros(H + 2, W + 2, C, device=dev, dtype=torch.bfloat16)
+            xpad[1:-1, 1:-1] = torch.randn(H, W, C, device=dev).to(torch.bfloat16)
+            wb = (torch.randn(9, O, C, device=dev) * (1.0 / (9 * C) ** 0.5)).to(torch.bfloat16)
+            bp = torch.zeros(O, device=dev)
+            z = torch.empty(H * s, W * s, Cn, device=dev, dtype=torch.bfloat16)
+            apad = torch.zeros(H * s + 2, W * s + 2, Cn, device=dev, dtype=torch.bfloat16) if li + 1 < len(geo) else None
+            keep = (xpad, wb, bp, z, apad)
 
-        def run():
-            _lib.check(lib.orn_conv3x3_ps_silu_fwd(_lib.ptr(x), _lib.ptr(wf), _lib.ptr(bf), 1, C, O, H, W, s, _lib.ptr(z),
-                                                   _lib.ptr(a), st))
+            def run():
+                _lib.check(lib.orn_conv_nhwc_bf16_fwd(c_void_p(xpad.data_ptr()), c_void_p(wb.data_ptr()), _lib.ptr(bp), H, W, C, O, s,
+                                                      c_void_p(z.data_ptr()), c_void_p(apad.data_ptr()) if apad is not None else None, st))
+        else:
+            x = torch.randn(1, C, H, W, device=dev)
+            wf = torch.randn(O, C, 3, 3, device=dev) * (1.0 / (9 * C) ** 0.5)
+            bf = torch.zeros(O, device=dev)
+            z = torch.empty(1, O // (s * s), H * s, W * s, device=dev)
+            a = torch.empty_like(z)
+            keep = (x, wf, bf, z, a)
+
+            def run():
+                _lib.check(lib.orn_conv3x3_ps_silu_fwd(_lib.ptr(x), _lib.ptr(wf), _lib.ptr(bf), 1, C, O, H, W, s, _lib.ptr(z),
+                                                       _lib.ptr(a), st))
         for _ in range(2):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -106,11 +125,11 @@ def conv_roofline(eng, precision, iters=10):
         e1.synchronize()
         dt = e0.elapsed_time(e1) / 1e3 / iters
         fl = 2.0 * C * 9 * O * H * W
-        per_layer.append(dict(layer=len(per_layer), ms=dt * 1e3, tflops=fl / dt / 1e12))
+        per_layer.append(dict(layer=li, ms=dt * 1e3, tflops=fl / dt / 1e12))
         tot_t += dt
         tot_f += fl
         n += 1
-        del x, wf, z, a
+        del keep
     return tot_f / n, tot_t / n, per_layer
 
 
@@ -142,7 +161,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=264)
     ap.add_argument('--warmup', type=int, default=66)
-    ap.add_argument('--precision', default=os.environ.get('ORN_PRECISION', 'fp32'), choices=['fp32', 'bf16'])
+    ap.add_argument('--precision', default=os.environ.get('ORN_PRECISION', 'bf16'), choices=['fp32', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     args = ap.parse_args()
@@ -198,7 +217,9 @@ def main():
                        'train_psnr_mean_timed_steps': psnr_last, 'finite': ok,
                        'whole_step_tflops': world * args.steps / dt * FLOP_STEP / 1e12},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'traffic': None, 'kernel': 'k_conv3x3_f32<EPI_PS_SILU> (5 launches/step, L0..L4)',
+                         'traffic': None,
+                         'kernel': ('k_conv3x3_f32<EPI_PS_SILU> (5 launches/step, L0..L4)' if args.precision == 'fp32'
+                                    else 'k_conv_nhwc_bf16<4,2,2,2,EPI_B_FWD> (3 launches/step, L2..L4)'),
                          'flops_per_launch': fl, 'avg_launch_ms': avg_dt * 1e3, 'per_layer': per_layer},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -846,3 +846,12 @@ extern "C" int orn_conv3x3_ps_silu_bwd_bf16(const float *x, const float *wf, con
     }
     return 0;
 }
+
+// Raw channels-last entry points (the engine's own layouts; used by bench.py's roofline leg).
+extern "C" int orn_conv_nhwc_bf16_fwd(const void *xpad, const void *wb, const float *bias_p, int H, int W, int C, int O,
+                                      int s, void *z, void *apad, void *stream)
+{
+    ORN_REQUIRE(xpad && wb && z, "conv_nhwc_bf16_fwd: null pointer");
+    return orn_launch_conv_bf16_fwd((const h16 *)xpad, (const h16 *)wb, bias_p, H, W, C, O, s, (h16 *)z, (h16 *)apad,
+                                    (hipStream_t)stream);
+}

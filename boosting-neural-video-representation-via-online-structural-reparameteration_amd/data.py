@@ -22,3 +22,26 @@ def synthetic_video(frames: int, h: int, w: int, seed: int = 1234, device='cuda'
     noise = torch.rand((frames, 3, h, w), generator=gd, device=device)
     v += 0.1 * (noise * 2 - 1)
     return v.clamp_(0, 1).contiguous()
+
+
+def load_png_dir(main_dir: str, vid_list=(None,), frame_gap: int = 1, device='cuda') -> torch.Tensor:
+    """CustomDataSet (model.py:11-70) without DataLoader workers: every `frame_gap`-th PNG of `main_dir`
+    (optionally filtered by video id prefix), ToTensor semantics (uint8/255 -> fp32 CHW), portrait frames
+    transposed to landscape (model.py:66-67), uploaded once and kept resident in HBM."""
+    import os
+    import numpy as np
+    from PIL import Image
+    names = sorted(f for f in os.listdir(main_dir) if f.lower().endswith(('.png', '.jpg', '.jpeg')))
+    if vid_list and vid_list[0] is not None:
+        names = [f for f in names if any(f.startswith(f'{v}_') or f.startswith(f'{v:03d}') for v in vid_list)]
+    names = names[::frame_gap]
+    if not names:
+        raise FileNotFoundError(f'no frames in {main_dir}')
+    frames = []
+    for f in names:
+        img = np.asarray(Image.open(os.path.join(main_dir, f)).convert('RGB'), dtype=np.uint8)
+        t = torch.from_numpy(img).permute(2, 0, 1)
+        if t.shape[1] > t.shape[2]:
+            t = t.permute(0, 2, 1)
+        frames.append(t)
+    return (torch.stack(frames).to(device).float() / 255.0).contiguous()

@@ -1,0 +1,200 @@
+"""`python -m orn_amd.main_train <flags>`: the reference's training CLI (main_train.py:38-157) driving
+the native engine.  Same flags; the data source is a synthetic video resident in HBM (`--synthetic N`)
+or a directory of PNG frames (`../data/<dataset>` as in main_train.py:202-203, needs PIL).
+
+Differences kept deliberately small and stated here: no tensorboard/thop (not in this image); the
+checkpoint is written every `--ckpt_freq` epochs (default: every eval epoch and the last) instead of
+every epoch, because an epoch takes a fraction of a second here; per-rank videos under
+torch.distributed.run (one independent fit per GPU, RCCL only for the final gather).
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+from . import data as odata
+from . import dist_utils as du
+from . import engine as oeng
+from . import model as omodel
+from . import ops, utils
+
+
+def build_parser():
+    p = argparse.ArgumentParser(fromfile_prefix_chars='@')
+    p.add_argument('--vid', default=[None], type=int, nargs='+')
+    p.add_argument('--scale', type=int, default=1)
+    p.add_argument('--frame_gap', type=int, default=1)
+    p.add_argument('--augment', type=int, default=0)
+    p.add_argument('--dataset', type=str, default='UVG')
+    p.add_argument('--test_gap', default=1, type=int)
+    p.add_argument('--embed', type=str, default='1.25_80')
+    p.add_argument('--stem_dim_num', type=str, default='1024_1')
+    p.add_argument('--fc_hw_dim', type=str, default='9_16_128')
+    p.add_argument('--expansion', type=float, default=8)
+    p.add_argument('--reduction', type=int, default=2)
+    p.add_argument('--strides', type=int, nargs='+', default=[5, 3, 2, 2, 2])
+    p.add_argument('--num_blocks', type=int, default=1)
+    p.add_argument('--norm', default='none', type=str, choices=['none', 'bn', 'in'])
+    p.add_argument('--act', type=str, default='gelu',
+                   choices=['relu', 'leaky', 'leaky01', 'relu6', 'gelu', 'swish', 'softplus', 'hardswish'])
+    p.add_argument('--lower_width', type=int, default=32)
+    p.add_argument('--single_res', action='store_true')
+    p.add_argument('--conv_type', default='conv', type=str, choices=['conv', 'deconv', 'bilinear'])
+    p.add_argument('--branch_type', default='NeRV_vanilla', type=str,
+                   choices=['NeRV_vanilla', 'ERB', 'ACB', 'RepVGG', 'DBB', 'ECB'])
+    p.add_argument('-j', '--workers', type=int, default=4)
+    p.add_argument('-b', '--batchSize', type=int, default=1)
+    p.add_argument('--not_resume_epoch', action='store_true')
+    p.add_argument('-e', '--epochs', type=int, default=150)
+    p.add_argument('--warmup', type=float, default=0.2)
+    p.add_argument('--lr', type=float, default=0.001)
+    p.add_argument('--lr_type', type=str, default='cosine')
+    p.add_argument('--lr_steps', default=[], type=float, nargs='+')
+    p.add_argument('--beta', type=float, default=0.5)
+    p.add_argument('--loss_type', type=str, default='L2')
+    p.add_argument('--lw', type=float, default=1.0)
+    p.add_argument('--sigmoid', action='store_true')
+    p.add_argument('--deploy', action='store_true', default=False)
+    p.add_argument('--eval_only', action='store_true', default=False)
+    p.add_argument('--eval_freq', type=int, default=50)
+    p.add_argument('--quant_bit', type=int, default=-1)
+    p.add_argument('--quant_axis', type=int, default=0)
+    p.add_argument('--dump_images', action='store_true', default=False)
+    p.add_argument('--eval_fps', action='store_true', default=False)
+    p.add_argument('--prune_steps', type=float, nargs='+', default=[0., ])
+    p.add_argument('--prune_ratio', type=float, default=1.0)
+    p.add_argument('--manualSeed', type=int, default=1)
+    p.add_argument('--init_method', default='tcp://127.0.0.1:9888', type=str)
+    p.add_argument('-d', '--distributed', action='store_true', default=False)
+    p.add_argument('--debug', action='store_true')
+    p.add_argument('-p', '--print_freq', default=50, type=int)
+    p.add_argument('--weight', default='None', type=str)
+    p.add_argument('--overwrite', action='store_true')
+    p.add_argument('--outf', default='unify')
+    p.add_argument('--suffix', default='')
+    # additions of this engine
+    p.add_argument('--precision', default='bf16', choices=['fp32', 'bf16'])
+    p.add_argument('--synthetic', type=int, default=0, help='use N synthetic frames in HBM instead of ../data/<dataset>')
+    p.add_argument('--ckpt_freq', type=int, default=0, help='checkpoint every K epochs (0: eval epochs and the last)')
+    return p
+
+
+def parse_args(argv=None):
+    args = build_parser().parse_args(argv)
+    args.warmup = int(args.warmup * args.epochs)                   # main_train.py:111
+    if args.debug:
+        args.eval_freq = 1
+        args.outf = 'result/debug'
+    else:
+        args.outf = os.path.join('result', args.outf)
+    args.outf = os.path.join(args.outf, f'{args.suffix}')          # main_train.py:138
+    return args
+
+
+def load_frames(args, hw, device):
+    if args.synthetic:
+        return odata.synthetic_video(args.synthetic, hw[0], hw[1], seed=1234 + du.env_world()[0], device=device)
+    return odata.load_png_dir(f'../data/{args.dataset.lower()}', args.vid, args.frame_gap, device)
+
+
+def save_checkpoint(args, model, eng, epoch, best_psnr, name='model_latest.pth'):
+    """main_train.py:293-301,327 layout; ERB also writes the deploy copy (main_train.py:325-351)."""
+    os.makedirs(args.outf, exist_ok=True)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    ck = {'epoch': epoch + 1, 'state_dict': sd, 'train_best_psnr': best_psnr, 'train_best_msssim': torch.tensor(0),
+          'val_best_psnr': best_psnr, 'val_best_msssim': torch.tensor(0),
+          'optimizer': {'adam_m': eng.adam_m.cpu(), 'adam_v': eng.adam_v.cpu(), 'step': eng.global_step, 'layout': eng.layout}}
+    torch.save(ck, os.path.join(args.outf, name))
+    if args.branch_type == 'ERB':
+        dsd = {k: v for k, v in sd.items() if not k.startswith('layers.')}
+        for i, blk in enumerate(model.layers):
+            with torch.no_grad():
+                wf, bf = blk.get_equivalent_kernel_bias()
+            dsd[f'layers.{i}.rbr_reparam.weight'] = wf.cpu()
+            dsd[f'layers.{i}.rbr_reparam.bias'] = bf.cpu()
+        ck_d = dict(ck, state_dict=dsd)
+        torch.save(ck_d, os.path.join(args.outf, name.replace('.pth', '_deploy.pth')))
+
+
+def evaluate(model, eng, args):
+    """main_train.py:377-438: forward over all frames, PSNR per frame, decoder FPS."""
+    n = eng.frames.shape[0]
+    psnrs = []
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for k in range(0, n, args.test_gap):
+        img = eng.decode(eng.embeds[k])
+        stats, _ = ops.loss_stats(img, eng.frames[k:k + 1], 'L2', want_grad=False)
+        psnrs.append(stats[4])
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    return float(torch.stack(psnrs).mean()), len(psnrs) / dt
+
+
+def train(args):
+    rank, local, world = du.env_world()
+    torch.cuda.set_device(local)
+    dist = du.init()
+    torch.manual_seed(args.manualSeed)                              # main_train.py:162
+    PE = utils.PositionalEncoding(args.embed)
+    args.embed_length = PE.embed_length
+    model = omodel.Generator(embed_length=args.embed_length, stem_dim_num=args.stem_dim_num, fc_hw_dim=args.fc_hw_dim,
+                             expansion=args.expansion, num_blocks=args.num_blocks, norm=args.norm, act=args.act, bias=True,
+                             reduction=args.reduction, conv_type=args.conv_type, stride_list=args.strides,
+                             sin_res=args.single_res, lower_width=args.lower_width, sigmoid=args.sigmoid,
+                             deploy=args.deploy, branch_type=args.branch_type)
+    total_params = sum(p.numel() for p in model.parameters()) / 1e6
+    eng = oeng.TrainEngine(model, loss_type=args.loss_type, beta=args.beta, precision=args.precision)
+    frames = load_frames(args, eng.out_hw, eng.device)
+    n = frames.shape[0]
+    pos = torch.tensor([float(k) / n for k in range(n)], dtype=torch.float32)      # model.py:37,68
+    eng.set_video(frames, PE(pos))
+    os.makedirs(args.outf, exist_ok=True)
+    log = open(os.path.join(args.outf, f'rank{rank}.txt'), 'a')
+    print(f'{args}\n Model Params: {total_params}M', file=log, flush=True)
+    g = torch.Generator()
+    best = torch.tensor(0.0)
+    start = time.time()
+    steps_per_epoch = min(n, 11) if args.debug else n
+    for epoch in range(args.epochs):
+        g.manual_seed(args.manualSeed + epoch)
+        order = torch.randperm(n, generator=g).tolist()[:steps_per_epoch]
+        entries = [(f, epoch * steps_per_epoch + i + 1, utils.lr_value(epoch % args.epochs, i, n, args)) for i, f in enumerate(order)]
+        eng.set_schedule(entries)
+        eng.run(len(entries))
+        st = eng.stats(len(entries))                                 # syncs once per epoch
+        train_psnr = st[:, 4].mean()
+        best = torch.maximum(best, train_psnr)
+        line = (f'[{time.strftime("%Y/%m/%d %H:%M:%S")}] Rank:{rank}, Epoch[{epoch + 1}/{args.epochs}], lr:{st[-1, 5]:.2e} '
+                f'PSNR: {train_psnr:.2f}, loss: {st[:, 0].mean():.5f}, {(time.time() - start) / (epoch + 1):.3f} s/epoch')
+        if epoch % max(1, args.print_freq // 10) == 0 or epoch == args.epochs - 1:
+            print(line, flush=True)
+        print(line, file=log, flush=True)
+        is_eval = (epoch + 1) % args.eval_freq == 0 or epoch > args.epochs - 10     # main_train.py:303
+        if is_eval:
+            val_psnr, fps = evaluate(model, eng, args)
+            msg = f'Eval Epoch[{epoch + 1}] PSNR {val_psnr:.2f} decode FPS {fps:.1f}'
+            print(msg, flush=True)
+            print(msg, file=log, flush=True)
+        if (args.ckpt_freq and (epoch + 1) % args.ckpt_freq == 0) or (not args.ckpt_freq and is_eval) or epoch == args.epochs - 1:
+            save_checkpoint(args, model, eng, epoch, best)
+    torch.cuda.synchronize()
+    secs = time.time() - start
+    recs = du.gather_records(dist, [float(best), 0.0, float(args.epochs * steps_per_epoch), secs, float(eng.global_step)],
+                             device=eng.device if dist is not None else 'cpu')
+    if rank == 0:
+        agg = du.aggregate(recs, max(r[3] for r in recs))
+        print(f'Training complete in {secs:.1f}s: {agg}', flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    return float(best)
+
+
+def main(argv=None):
+    train(parse_args(argv))
+
+
+if __name__ == '__main__':
+    main()

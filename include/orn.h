@@ -92,6 +92,12 @@ int orn_conv3x3_ps_silu_bwd_bf16(const float *x, const float *wf, const float *z
                                  int H, int W, int s, float *dx, float *dwf, float *dbf, void *ws,
                                  size_t ws_bytes, void *stream);
 
+/* The forward conv kernel on the engine's own channels-last bf16 buffers (DESIGN.md "data layout"):
+ * xpad [H+2][W+2][C] zero-bordered, wb [9][O'][C], bias_p [O'] (o' = (i*s+j)*Cn + n), z [H*s][W*s][Cn],
+ * apad [H*s+2][W*s+2][Cn] or NULL.  This is the dominant kernel bench.py prices against the MFMA roofline. */
+int orn_conv_nhwc_bf16_fwd(const void *xpad, const void *wb, const float *bias_p, int H, int W, int C, int O,
+                           int s, void *z, void *apad, void *stream);
+
 /* ---- A5  head: 1x1 conv -> (tanh+1)/2 or sigmoid                      model.py:621-622 --------
  * a [B,C,H,W]; w [3,C,1,1]; b [3]; out [B,3,H,W]. */
 int orn_head_fwd(const float *a, const float *w, const float *b, int B, int C, int H, int W, int sigmoid,

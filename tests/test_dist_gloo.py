@@ -1,0 +1,62 @@
+"""N>1 path on CPU: world_size-2 gloo run of the sharding / timing / gather plumbing bench.py and the
+CLI use on the GPU box over RCCL."""
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["ORN_ROOT"])
+import torch
+import orn_amd
+from orn_amd import dist_utils as du
+rank, local, world = du.env_world()
+dist = du.init("gloo")
+assert dist is not None and dist.get_world_size() == 2
+vids = du.shard_videos(7, world, rank)
+assert vids == ([0, 2, 4, 6] if rank == 0 else [1, 3, 5])
+dt = du.max_over_ranks(dist, 1.0 + rank)          # rank 1 is slower
+assert dt == 2.0, dt
+recs = du.gather_records(dist, [30.0 + rank, 0.9, 100.0 * (rank + 1), 1.0 + rank, 100 * (rank + 1)])
+assert len(recs) == 2 and recs[0][0] == 30.0 and recs[1][0] == 31.0
+agg = du.aggregate(recs, dt)
+assert abs(agg["frames_per_s"] - 150.0) < 1e-6 and agg["ranks"] == 2
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_gloo(tmp_path):
+    port = _free_port()
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), ORN_ROOT=ROOT, OMP_NUM_THREADS='1')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert f'rank {rank} ok' in out
+
+
+def test_shard_videos_single_process():
+    sys.path.insert(0, ROOT)
+    from orn_amd import dist_utils as du
+    seen = sorted(v for r in range(8) for v in du.shard_videos(7, 8, r))
+    assert seen == list(range(7)) and du.shard_videos(7, 8, 7) == []
+    assert du.max_over_ranks(None, 3.5) == 3.5
+    assert du.gather_records(None, [1, 2, 3, 4, 5]) == [[1.0, 2.0, 3.0, 4.0, 5.0]]

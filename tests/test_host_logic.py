@@ -1,0 +1,124 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/orn.h declares,
+the engine descriptor / arena layout / schedule encoding, and the LR schedule vs the golden table."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def orn():
+    import orn_amd
+    from orn_amd import _build
+    _build.build()
+    return orn_amd
+
+
+def test_library_exports_every_declared_symbol(orn):
+    hdr = open(os.path.join(ROOT, 'include', 'orn.h')).read()
+    declared = set(re.findall(r'\b(orn_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'orn_layer_desc', 'orn_engine_desc', 'orn_step_sched'}
+    L = orn._lib.lib()                       # resolves every name in _lib._SIGS (raises if one is missing)
+    assert declared == set(orn._lib.EXPORTS), declared ^ set(orn._lib.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name)
+    assert L.orn_version() == 100
+    # argument errors come back as codes + text, not exceptions across the ABI (no GPU needed)
+    assert L.orn_pe_fwd(None, 0, None, 0, None, None) == -1
+    assert 'pe_fwd' in orn._lib.last_error()
+    assert L.orn_engine_ws_bytes(None) == 0
+
+
+def test_missing_library_fails_loudly(orn, monkeypatch):
+    monkeypatch.setattr(orn._lib, '_lib', None)
+    monkeypatch.setattr(orn._lib, 'lib_path', lambda: '/nonexistent/liborn.so')
+    with pytest.raises(orn.OrnError):
+        orn._lib.lib()
+
+
+def test_cpu_tensors_are_rejected(orn):
+    from orn_amd import ops
+    with pytest.raises(orn.OrnError):
+        ops.ConvPsSiluFn.apply(torch.zeros(1, 4, 4, 4), torch.zeros(16, 4, 3, 3), torch.zeros(16), 2)
+    with pytest.raises(orn.OrnError):
+        ops.loss_stats(torch.zeros(1, 3, 16, 16), torch.zeros(1, 3, 16, 16), 'L2')
+
+
+def _gen(orn, bt='ERB', deploy=False):
+    from orn_amd import model
+    torch.manual_seed(1)
+    return model.Generator(embed_length=80, stem_dim_num='512_1', fc_hw_dim='9_16_26', expansion=1, num_blocks=1,
+                           norm='none', act='swish', bias=True, reduction=2, conv_type='conv', stride_list=[5, 2, 2, 2, 2],
+                           sin_res=True, lower_width=96, sigmoid=False, deploy=deploy, branch_type=bt)
+
+
+def test_generator_mirror_matches_reference_layout(orn, golden):
+    g = golden('generator')
+    gen = _gen(orn)
+    sd = gen.state_dict()
+    assert list(sd.keys()) == list(g['p720/keys'])                   # 51 tensors, reference key order
+    assert sum(p.numel() for p in gen.parameters()) == 7576025
+    for i, (k, v) in enumerate(sd.items()):                          # same seeded init as main_train.py:162
+        assert str(tuple(v.shape)) == g['p720/shapes'][i]
+        assert np.array_equal(np.resize(v.numpy().reshape(-1)[:8], 8), g['p720/param_first8'][i]), k
+    assert hasattr(gen.layers[0], 'rbr_3x3_branch') and gen.stem[0].in_features == 80
+    dep = _gen(orn, deploy=True)
+    assert [k for k in dep.state_dict() if k.startswith('layers.0')] == ['layers.0.rbr_reparam.weight', 'layers.0.rbr_reparam.bias']
+    assert sum(p.numel() for p in dep.parameters()) == 3201905
+    with pytest.raises(NotImplementedError):
+        from orn_amd import model
+        model.NeRVBlock(ngf=4, new_ngf=4, stride=2, bias=True, norm='none', act='swish', deploy=False, conv_type='conv',
+                        branch_type='DBB')
+
+
+def test_engine_descriptor_and_arena(orn):
+    from orn_amd import engine
+    gen = _gen(orn)
+    named = [(k, tuple(p.shape)) for k, p in gen.named_parameters()]
+    layout, total = engine.arena_layout(named)
+    assert total % 64 == 0 and all(off % 64 == 0 for off, _ in layout.values())
+    offs = sorted(layout.values())
+    for (o0, n0), (o1, _) in zip(offs, offs[1:]):
+        assert o0 + n0 <= o1                                          # no overlap
+    d = engine.build_desc(gen, layout, total, 'Fusion6', 0.5)
+    assert (d.n_layers, d.erb, d.embed_len, d.stem_dim, d.fc_h, d.fc_w, d.fc_dim) == (5, 1, 80, 512, 9, 16, 26)
+    geo = [(L.C, L.O, L.s, L.H, L.W) for L in list(d.layer)[:5]]
+    assert geo == [(26, 650, 5, 9, 16), (26, 384, 2, 45, 80), (96, 384, 2, 90, 160), (96, 384, 2, 180, 320), (96, 384, 2, 360, 640)]
+    assert d.layer[4].w3 == layout['layers.4.rbr_1x1_3x3_1x1_branch_1x1_2.weight'][0]
+    assert d.head_w == layout['head_layers.4.weight'][0] and d.loss_type == 2 and d.beta1 == 0.5
+    assert orn._lib.lib().orn_engine_ws_bytes(d) > 0                 # geometry accepted by the native side
+    d.layer[2].H = 91
+    assert orn._lib.lib().orn_engine_ws_bytes(d) == 0 and 'does not chain' in orn._lib.last_error()
+    van = _gen(orn, 'NeRV_vanilla')
+    lv, tv = engine.arena_layout([(k, tuple(p.shape)) for k, p in van.named_parameters()])
+    dv = engine.build_desc(van, lv, tv)
+    assert dv.erb == 0 and dv.layer[0].w3x3 == lv['layers.0.branch.weight'][0] and dv.layer[0].w1 == -1
+
+
+def test_schedule_encoding(orn):
+    from orn_amd import engine
+    arr = engine.make_schedule([(3, 1, 5e-4), (131, 39600, 1.229e-12)])
+    assert arr.dtype == np.int32 and arr.shape == (2, 4)
+    assert arr[1, 0] == 131 and arr[1, 1] == 39600
+    assert arr[:, 2].view(np.float32)[0] == np.float32(5e-4)
+
+
+def test_lr_schedule_matches_reference(orn, golden):
+    from orn_amd import utils
+
+    class A:
+        lr, epochs, warmup, lr_steps = 5e-4, 300, 60, []
+    g = golden('utils')
+    for kind, e, it, val in g['lr/table']:
+        A.lr_type = 'cosine' if kind == 0 else 'const'
+        assert utils.lr_value(int(e), int(it), 132, A) == val
+    opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))])
+    A.lr_type = 'cosine'
+    assert utils.adjust_lr(opt, 30, 0, 132, A) == pytest.approx(2.75e-4) and opt.param_groups[0]['lr'] == pytest.approx(2.75e-4)
+    pe = utils.PositionalEncoding('1.25_40')
+    assert pe.embed_length == 80 and pe.lbase == 1.25 and pe.levels == 40
