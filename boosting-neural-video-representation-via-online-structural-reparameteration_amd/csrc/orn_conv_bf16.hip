@@ -36,12 +36,37 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 enum { EPI_B_FWD = 0, EPI_B_DGRAD = 1, EPI_B_DGRAD_F32 = 2 };
 
+typedef __attribute__((ext_vector_type(2))) __bf16 h16x2;
+__device__ __forceinline__ unsigned pack_h16x2(float lo, float hi)
+{
+    h16x2 v;
+    v[0] = (h16)lo;
+    v[1] = (h16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+// v_permlane32_swap: lanes 32-63 of `a` <-> lanes 0-31 of `b` (guide T21).  After the call lanes < 32
+// hold (own a, upper half's a) and lanes >= 32 hold (lower half's b, own b).
+__device__ __forceinline__ void swap_halves(unsigned &a, unsigned &b)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+__device__ __forceinline__ void swap_halves_f(float &a, float &b)
+{
+    unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
+    swap_halves(ua, ub);
+    a = __builtin_bit_cast(float, ua);
+    b = __builtin_bit_cast(float, ub);
+}
+
 struct ConvBP {
     const h16 *xpad;     // [H+2][W+2][Cin]
     const h16 *w;        // [9][Nout][Cin]
     const float *bias;   // [Nout] (o' order) or null
     int H, W, Cin, Nout;
     int tiles_w, tiles_h, n_tiles_per_wg;
+    int n_full;          // work-groups [0, n_full) own whole pixel tiles; the rest own one N tile each
     // EPI_B_FWD
     h16 *z;              // [H*s][W*s][Cn]
     h16 *apad;           // [H*s+2][W*s+2][Cn] or null
@@ -52,6 +77,7 @@ struct ConvBP {
     int sp;
     // EPI_B_DGRAD_F32
     float *dx_f32;       // [H][W][Nout]
+    int dbg;             // timing-only ablation flags (tools/probes): 1 no weight restage, 2 no patch stage, 4 no stores
 };
 
 template <int WAVES_M, int WAVES_N, int MB, int NB, int EPI>
@@ -68,50 +94,82 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int tile = blockIdx.x;
+    // work list: the first n_full work-groups take a pixel tile with all its N tiles; the pixel tiles of the
+    // last partial round are cut into single-N-tile work-groups so the tail spreads over every CU
+    int tile = blockIdx.x, nt0 = blockIdx.y * p.n_tiles_per_wg, nt_cnt = p.n_tiles_per_wg;
+    if ((int)blockIdx.x >= p.n_full) {
+        const int r = blockIdx.x - p.n_full;
+        tile = p.n_full + r / p.n_tiles_per_wg;
+        nt0 = r - (r / p.n_tiles_per_wg) * p.n_tiles_per_wg;
+        nt_cnt = 1;
+    }
     const int tw = tile % p.tiles_w, th = tile / p.tiles_w;
     const int h0 = th * CB_TH, w0 = tw * CB_TW;
     const int H = p.H, W = p.W, Cin = p.Cin;
     const int Q = Cin / CB_CK;
-    const int nt0 = blockIdx.y * p.n_tiles_per_wg;
     const int n_tiles = Q * 9;                         // weight tiles per N tile
 
     constexpr int B_CHUNKS = BN * 12;                  // 16-byte chunks per weight tile
     constexpr int B_PER_THR = (B_CHUNKS + NT - 1) / NT;
     u32x4 breg[B_PER_THR];
+    int b_goff[B_PER_THR], b_loff[B_PER_THR];          // loop-invariant per-thread global / LDS offsets
+#pragma unroll
+    for (int it = 0; it < B_PER_THR; ++it) {
+        const int idx = t + it * NT;
+        const int row = idx / 12, ch = idx - row * 12;
+        b_goff[it] = row * Cin + ch * 8;
+        b_loff[it] = row * CB_ROWB + ch * 16;
+    }
 
     // weight-tile staging through registers (macros, not lambdas: the register array must stay in VGPRs)
 #define LOAD_B(nt_, q_, tap_)                                                                                   \
-    _Pragma("unroll") for (int it = 0; it < B_PER_THR; ++it) {                                                  \
-        const int idx = t + it * NT;                                                                            \
-        if (B_CHUNKS % NT == 0 || idx < B_CHUNKS) {                                                             \
-            const int row = idx / 12, ch = idx - row * 12;                                                      \
-            breg[it] = *reinterpret_cast<const u32x4 *>(                                                        \
-                p.w + ((size_t)((tap_) * p.Nout + (nt_) * BN + row) * Cin + (q_) * CB_CK + ch * 8));            \
-        }                                                                                                       \
+    {                                                                                                           \
+        const h16 *wbase = p.w + ((size_t)((tap_) * p.Nout + (nt_) * BN) * Cin + (q_) * CB_CK);                 \
+        _Pragma("unroll") for (int it = 0; it < B_PER_THR; ++it)                                                \
+            if (B_CHUNKS % NT == 0 || t + it * NT < B_CHUNKS)                                                   \
+                breg[it] = *reinterpret_cast<const u32x4 *>(wbase + b_goff[it]);                                \
     }
 #define STORE_B(buf_)                                                                                           \
-    _Pragma("unroll") for (int it = 0; it < B_PER_THR; ++it) {                                                  \
-        const int idx = t + it * NT;                                                                            \
-        if (B_CHUNKS % NT == 0 || idx < B_CHUNKS) {                                                             \
-            const int row = idx / 12, ch = idx - row * 12;                                                      \
-            *reinterpret_cast<u32x4 *>(bs0 + (buf_) * BS_BYTES + row * CB_ROWB + ch * 16) = breg[it];           \
+    {                                                                                                           \
+        unsigned char *lbase = bs0 + (buf_) * BS_BYTES;                                                         \
+        _Pragma("unroll") for (int it = 0; it < B_PER_THR; ++it)                                                \
+            if (B_CHUNKS % NT == 0 || t + it * NT < B_CHUNKS)                                                   \
+                *reinterpret_cast<u32x4 *>(lbase + b_loff[it]) = breg[it];                                      \
+    }
+    // patch staging: all global loads in flight first, then the LDS writes (one latency, not eight)
+    constexpr int P_CHUNKS = CB_PH * CB_PW * 12;
+    constexpr int P_PER_THR = (P_CHUNKS + NT - 1) / NT;
+#define STAGE_PATCH(q_)                                                                                         \
+    {                                                                                                           \
+        u32x4 pv[P_PER_THR];                                                                                    \
+        _Pragma("unroll") for (int it = 0; it < P_PER_THR; ++it) {                                              \
+            const int idx = t + it * NT;                                                                        \
+            const int pix = idx / 12, ch = idx - pix * 12;                                                      \
+            const int pr = pix / CB_PW, pc = pix - pr * CB_PW;                                                  \
+            const int gh = h0 + pr, gw_ = w0 + pc;                                                              \
+            pv[it] = u32x4{0u, 0u, 0u, 0u};                                                                     \
+            if (idx < P_CHUNKS && gh < H + 2 && gw_ < W + 2)                                                    \
+                pv[it] = *reinterpret_cast<const u32x4 *>(p.xpad + ((size_t)gh * (W + 2) + gw_) * Cin + (q_) * CB_CK + ch * 8); \
+        }                                                                                                       \
+        _Pragma("unroll") for (int it = 0; it < P_PER_THR; ++it) {                                              \
+            const int idx = t + it * NT;                                                                        \
+            const int pix = idx / 12, ch = idx - pix * 12;                                                      \
+            if (idx < P_CHUNKS) *reinterpret_cast<u32x4 *>(patch + pix * CB_PIXB + ch * 16) = pv[it];           \
         }                                                                                                       \
     }
-    auto stage_patch = [&](int q) {
-        for (int idx = t; idx < CB_PH * CB_PW * 12; idx += NT) {
-            const int pix = idx / 12, ch = idx - pix * 12;
-            const int pr = pix / CB_PW, pc = pix - pr * CB_PW;
-            const int gh = h0 + pr, gw = w0 + pc;          // padded coords
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (gh < H + 2 && gw < W + 2)
-                v = *reinterpret_cast<const uint4 *>(p.xpad + ((size_t)gh * (W + 2) + gw) * Cin + q * CB_CK + ch * 8);
-            *reinterpret_cast<uint4 *>(patch + pix * CB_PIXB + ch * 16) = v;
-        }
-    };
+#define READ_FRAGS(A_, B_, buf_, pa_, ks_)                                                                      \
+    {                                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < MB; ++i)                                                          \
+            A_[i] = *reinterpret_cast<const h16x8 *>((pa_) + i * CB_PW * CB_PIXB + (ks_) * 32);                 \
+        _Pragma("unroll") for (int j = 0; j < NB; ++j)                                                          \
+            B_[j] = *reinterpret_cast<const h16x8 *>(bs0 + (buf_) * BS_BYTES + boff + j * 32 * CB_ROWB + (ks_) * 32); \
+    }
 
-    for (int nti = 0; nti < p.n_tiles_per_wg; ++nti) {
+    bool next_b_loaded = false;
+    for (int nti = 0; nti < nt_cnt; ++nti) {
         const int nt = nt0 + nti;
+        // acc[i][j]: D rows = 32 output channels (A operand = weights), D cols = 32 pixels of one row
+        // (B operand = input patch): each lane owns ONE pixel and 16 channels in groups of 4 consecutive.
         f32x16 acc[MB][NB];
 #pragma unroll
         for (int i = 0; i < MB; ++i)
@@ -120,78 +178,128 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        // prologue: first weight tile (+ patch when it is not already resident)
-        LOAD_B(nt, 0, 0)
+        // prologue: weight tiles 0 and 1 (+ the patch when it is not already resident).  Three LDS weight
+        // buffers: tile t+2 is written while tile t computes, so tile t+1 is complete one barrier
+        // early and its first fragments can be read BEFORE the barrier that ends tile t -- the matrix
+        // pipe does not drain at the per-tap barrier.
+        const int boff = (wn * NB * 32 + l31) * CB_ROWB + hh * 16;
+        if (!next_b_loaded) { LOAD_B(nt, 0, 0) }
+        next_b_loaded = false;
         if (nti == 0 || Q > 1) {
             __syncthreads();
-            stage_patch(0);
+            if (!(p.dbg & 2)) STAGE_PATCH(0)
         }
         STORE_B(0)
+        if (n_tiles > 1) {
+            LOAD_B(nt, 0, 1)
+            STORE_B(1)
+        }
         __syncthreads();
-        int cur = 0;
+        if (n_tiles > 2) { LOAD_B(nt, 0, 2) }
+        h16x8 fa[2][MB], fb[2][NB];
+        {
+            const unsigned char *pa0 = patch + ((wm * MB + 0) * CB_PW + (l31 + 0)) * CB_PIXB + hh * 16;
+            READ_FRAGS(fa[0], fb[0], 0, pa0, 0)
+        }
+        int buf = 0;
         for (int tt = 0; tt < n_tiles; ++tt) {
             const int q = tt / 9, tap = tt - q * 9;
             const int ti = tap / 3, tj = tap - ti * 3;
             const bool has_next = (tt + 1 < n_tiles);
             const int qn = (tt + 1) / 9, tapn = (tt + 1) - qn * 9;
-            if (has_next) { LOAD_B(nt, qn, tapn) }
-            const unsigned char *bsb = bs0 + cur * BS_BYTES + (wn * NB * 32 + l31) * CB_ROWB + hh * 16;
+            const int tin = tapn / 3, tjn = tapn - tin * 3;
+            const bool same_chunk = has_next && (qn == q);
+            const int bufn = (buf == 2) ? 0 : buf + 1;
             const unsigned char *pa = patch + ((wm * MB + ti) * CB_PW + (l31 + tj)) * CB_PIXB + hh * 16;
+            const unsigned char *pan = patch + ((wm * MB + tin) * CB_PW + (l31 + tjn)) * CB_PIXB + hh * 16;
 #pragma unroll
             for (int ks = 0; ks < CB_CK / 16; ++ks) {
-                h16x8 a[MB], b[NB];
-#pragma unroll
-                for (int i = 0; i < MB; ++i) a[i] = *reinterpret_cast<const h16x8 *>(pa + i * CB_PW * CB_PIXB + ks * 32);
-#pragma unroll
-                for (int j = 0; j < NB; ++j) b[j] = *reinterpret_cast<const h16x8 *>(bsb + j * 32 * CB_ROWB + ks * 32);
+                if (!(p.dbg & 16)) {
+                    if (ks + 1 < CB_CK / 16) READ_FRAGS(fa[(ks + 1) & 1], fb[(ks + 1) & 1], buf, pa, ks + 1)
+                    else if (same_chunk) READ_FRAGS(fa[0], fb[0], bufn, pan, 0)
+                }
 #pragma unroll
                 for (int i = 0; i < MB; ++i)
 #pragma unroll
-                    for (int j = 0; j < NB; ++j) acc[i][j] = MFMA_H16(a[i], b[j], acc[i][j]);
+                    for (int j = 0; j < NB; ++j) acc[i][j] = MFMA_H16(fb[ks & 1][j], fa[ks & 1][i], acc[i][j]);
             }
-            if (has_next) {
-                if (qn != q) {            // next chunk needs a new patch: everyone must be done reading
-                    __syncthreads();
-                    stage_patch(qn);
-                }
-                STORE_B(cur ^ 1)
+            if (tt + 2 < n_tiles && !(p.dbg & 1)) { STORE_B((buf + 2) % 3) }
+            if (has_next && !same_chunk) {            // next chunk needs a new patch: everyone must be done reading
+                __syncthreads();
+                if (!(p.dbg & 2)) STAGE_PATCH(qn)
             }
-            __syncthreads();
-            cur ^= 1;
+            if (!(p.dbg & 8)) __syncthreads();
+            if (tt + 3 < n_tiles && !(p.dbg & 1)) {
+                const int q3 = (tt + 3) / 9, tap3 = (tt + 3) - q3 * 9;
+                LOAD_B(nt, q3, tap3)
+            }
+            if (has_next && !same_chunk) READ_FRAGS(fa[0], fb[0], bufn, pan, 0)
+            buf = bufn;
+        }
+        // next N tile's first weight tile goes in flight before the epilogue's stores
+        if (nti + 1 < nt_cnt) {
+            LOAD_B(nt + 1, 0, 0)
+            next_b_loaded = true;
         }
 
         // ---- epilogue --------------------------------------------------------------------------
+        // Lane (pixel l31, half hh) holds channels 8g + 4hh + e (g = reg>>2, e = reg&3) of each 32-ch block.
+        // v_permlane32_swap pairs the two half-waves so that every lane ends up with 8 CONSECUTIVE
+        // channels of its pixel (lanes <32: group pair's first 8, lanes >=32: the next 8): 16-byte stores.
+        const int gw = w0 + l31;
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
             const int gh = h0 + wm * MB + i;
-            if (gh >= H) continue;
+            const bool ok = (gh < H) && (gw < W) && !(p.dbg & 4);
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const int oc = nt * BN + (wn * NB + j) * 32 + l31;       // output channel (o' for fwd)
-                float bv = 0.f;
-                if (EPI == EPI_B_FWD && p.bias) bv = p.bias[oc];
-                int ij = 0, n = 0, si = 0, sj = 0;
-                if (EPI == EPI_B_FWD) { ij = oc / p.Cn; n = oc - ij * p.Cn; si = ij / p.s; sj = ij - si * p.s; }
+                const int cb = nt * BN + (wn * NB + j) * 32;            // first output channel of the block
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int gw = w0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-                    if (gw >= W) continue;
-                    const float v = acc[i][j][reg] + bv;
+                for (int k = 0; k < 4; k += 2) {
+                    const int c8 = cb + 8 * (k + hh);                   // the 8 channels this lane stores
                     if (EPI == EPI_B_FWD) {
-                        const int Hs = H * p.s, Ws = W * p.s;
-                        const int oh = gh * p.s + si, ow = gw * p.s + sj;
-                        (void)Hs;
-                        p.z[((size_t)oh * Ws + ow) * p.Cn + n] = (h16)v;
-                        if (p.apad) p.apad[((size_t)(oh + 1) * (Ws + 2) + (ow + 1)) * p.Cn + n] = (h16)orn_silu(v);
-                    } else if (EPI == EPI_B_DGRAD) {
-                        const float zz = (float)p.zprev[((size_t)gh * W + gw) * p.Nout + oc];
-                        const int sp = p.sp;
-                        const int ph = gh / sp, pw = gw / sp;
-                        const int sub = (gh - ph * sp) * sp + (gw - pw * sp);
-                        p.dyprev[((size_t)(ph + 1) * (W / sp + 2) + (pw + 1)) * (p.Nout * sp * sp) + sub * p.Nout + oc] =
-                            (h16)(v * orn_silu_grad(zz));
+                        float va[4], vb[4];
+                        const float4 ba = p.bias ? *reinterpret_cast<const float4 *>(p.bias + cb + 8 * k + 4 * hh) : make_float4(0, 0, 0, 0);
+                        const float4 bb = p.bias ? *reinterpret_cast<const float4 *>(p.bias + cb + 8 * (k + 1) + 4 * hh) : make_float4(0, 0, 0, 0);
+                        va[0] = acc[i][j][4 * k + 0] + ba.x; va[1] = acc[i][j][4 * k + 1] + ba.y;
+                        va[2] = acc[i][j][4 * k + 2] + ba.z; va[3] = acc[i][j][4 * k + 3] + ba.w;
+                        vb[0] = acc[i][j][4 * k + 4] + bb.x; vb[1] = acc[i][j][4 * k + 5] + bb.y;
+                        vb[2] = acc[i][j][4 * k + 6] + bb.z; vb[3] = acc[i][j][4 * k + 7] + bb.w;
+                        unsigned za0 = pack_h16x2(va[0], va[1]), za1 = pack_h16x2(va[2], va[3]);
+                        unsigned zb0 = pack_h16x2(vb[0], vb[1]), zb1 = pack_h16x2(vb[2], vb[3]);
+                        swap_halves(za0, zb0); swap_halves(za1, zb1);
+                        const int ij = c8 / p.Cn, n = c8 - ij * p.Cn, si = ij / p.s, sj = ij - si * p.s;
+                        const int Ws = W * p.s, oh = gh * p.s + si, ow = gw * p.s + sj;
+                        if (ok) *reinterpret_cast<u32x4 *>(p.z + ((size_t)oh * Ws + ow) * p.Cn + n) = u32x4{za0, za1, zb0, zb1};
+                        if (p.apad) {
+                            unsigned aa0 = pack_h16x2(orn_silu(va[0]), orn_silu(va[1])), aa1 = pack_h16x2(orn_silu(va[2]), orn_silu(va[3]));
+                            unsigned ab0 = pack_h16x2(orn_silu(vb[0]), orn_silu(vb[1])), ab1 = pack_h16x2(orn_silu(vb[2]), orn_silu(vb[3]));
+                            swap_halves(aa0, ab0); swap_halves(aa1, ab1);
+                            if (ok) *reinterpret_cast<u32x4 *>(p.apad + ((size_t)(oh + 1) * (Ws + 2) + (ow + 1)) * p.Cn + n) = u32x4{aa0, aa1, ab0, ab1};
+                        }
                     } else {
-                        p.dx_f32[((size_t)gh * W + gw) * p.Nout + oc] = v;
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float x0 = acc[i][j][4 * k + e], x1 = acc[i][j][4 * k + 4 + e];
+                            swap_halves_f(x0, x1);
+                            v[e] = x0; v[4 + e] = x1;
+                        }
+                        if (EPI == EPI_B_DGRAD) {
+                            if (ok) {
+                                const h16x8 zz = *reinterpret_cast<const h16x8 *>(p.zprev + ((size_t)gh * W + gw) * p.Nout + c8);
+                                h16x8 o8;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) o8[e] = (h16)(v[e] * orn_silu_grad((float)zz[e]));
+                                const int sp = p.sp, ph = gh / sp, pw = gw / sp, sub = (gh - ph * sp) * sp + (gw - pw * sp);
+                                *reinterpret_cast<h16x8 *>(p.dyprev + ((size_t)(ph + 1) * (W / sp + 2) + (pw + 1)) * (p.Nout * sp * sp) +
+                                                           sub * p.Nout + c8) = o8;
+                            }
+                        } else if (ok) {
+                            float *dst = p.dx_f32 + ((size_t)gh * W + gw) * p.Nout + c8;
+                            *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                            *reinterpret_cast<float4 *>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                        }
                     }
                 }
             }
@@ -201,13 +309,15 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
 
 #undef LOAD_B
 #undef STORE_B
+#undef STAGE_PATCH
+#undef READ_FRAGS
 
 template <int WAVES_M, int WAVES_N, int MB, int NB, int EPI>
 static int launch_conv_cfg(const ConvBP &p, int n_tiles_total, hipStream_t st)
 {
     constexpr int BN = WAVES_N * NB * 32;
     constexpr int NT = WAVES_M * WAVES_N * 64;
-    const size_t smem = CB_PATCH_BYTES + 2 * (size_t)BN * CB_ROWB;
+    const size_t smem = CB_PATCH_BYTES + 3 * (size_t)BN * CB_ROWB;
     auto kern = k_conv_nhwc_bf16<WAVES_M, WAVES_N, MB, NB, EPI>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -215,11 +325,22 @@ static int launch_conv_cfg(const ConvBP &p, int n_tiles_total, hipStream_t st)
         if (e != hipSuccess) { orn_set_error("conv_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
-    dim3 grid(p.tiles_w * p.tiles_h, n_tiles_total / p.n_tiles_per_wg);
-    hipLaunchKernelGGL(kern, grid, dim3(NT), smem, st, p);
+    const int ptiles = p.tiles_w * p.tiles_h;
+    ConvBP q = p;
+    dim3 grid(ptiles, n_tiles_total / p.n_tiles_per_wg);
+    q.n_full = ptiles;
+    if (p.n_tiles_per_wg > 1 && p.n_tiles_per_wg == n_tiles_total) {
+        // 256 CUs, one work-group each: whole rounds keep full tiles, the last partial round is cut up
+        q.n_full = ptiles / 256 * 256;
+        grid = dim3(q.n_full + (ptiles - q.n_full) * p.n_tiles_per_wg, 1);
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(NT), smem, st, q);
     ORN_LAUNCH_CHECK("conv_nhwc_bf16");
     return 0;
 }
+
+static int g_conv_dbg = 0;
+extern "C" void orn_debug_set(int flags) { g_conv_dbg = flags; }   // timing experiments only (tools/probes)
 
 // fwd: N tile 128 (waves 4x2, wave tile 64 px x 64 ch); dgrad: N = 96 in one tile (waves 8x1, 32 px x 96 ch)
 int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p, int H, int W, int Cin, int O, int s,
@@ -227,6 +348,7 @@ int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p
 {
     ORN_REQUIRE(Cin % CB_CK == 0 && O % 128 == 0 && O % (s * s) == 0, "conv_bf16_fwd: unsupported Cin=%d O=%d s=%d", Cin, O, s);
     ConvBP p = {};
+    p.dbg = g_conv_dbg;
     p.xpad = xpad; p.w = wb; p.bias = bias_p; p.H = H; p.W = W; p.Cin = Cin; p.Nout = O;
     p.tiles_w = orn_cdiv(W, CB_TW); p.tiles_h = orn_cdiv(H, CB_TH);
     p.z = z; p.apad = apad; p.s = s; p.Cn = O / (s * s);
@@ -241,6 +363,7 @@ int orn_launch_conv_bf16_dgrad(const h16 *dypad, const h16 *wd, int H, int W, in
 {
     ORN_REQUIRE(O % CB_CK == 0 && C == 96, "conv_bf16_dgrad: unsupported O=%d C=%d", O, C);
     ConvBP p = {};
+    p.dbg = g_conv_dbg;
     p.xpad = dypad; p.w = wd; p.bias = nullptr; p.H = H; p.W = W; p.Cin = O; p.Nout = C;
     p.tiles_w = orn_cdiv(W, CB_TW); p.tiles_h = orn_cdiv(H, CB_TH);
     p.n_tiles_per_wg = 1;

@@ -8,6 +8,7 @@
 
 struct LayerBuf {
     float *T, *wf, *bf;   // merge products (ERB) -- wf/bf alias the params for vanilla/deploy
+    float *dT, *dw1p;     // merge backward scratch (ERB)
     float *z, *a;         // block output (pre-activation, activation)          [fp32 layers]
     float *da;            // gradient wrt the block output                       [fp32 layers]
     // bf16 fast path (precision 1, layers >= ff): channels-last bf16, see orn_conv_bf16.hip
@@ -30,6 +31,8 @@ struct orn_engine {
     OrnStepCur *cur;                 // state of the step in flight (device)
     LayerBuf L[ORN_MAX_LAYERS];
     int Hout, Wout, Cn_last;
+    void *merge_tables;              // device-resident grouped-GEMM problem tables (ERB)
+    int merge_tiles[4];
     int ff;                          // first layer on the bf16 fast path (== n_layers: none)
     float *dxn;                      // fp32 NHWC dgrad output of layer ff (converted to NCHW for the fp32 part)
     // graph cache (one captured train step)
@@ -103,7 +106,10 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
     for (int i = 0; i < d->n_layers; ++i) {
         const orn_layer_desc &l = d->layer[i];
         const size_t wsz = (size_t)l.O * l.C * 9;
-        if (d->erb) { L[i].T = take(wsz); L[i].wf = take(wsz); L[i].bf = take(l.O); }
+        if (d->erb) {
+            L[i].T = take(wsz); L[i].wf = take(wsz); L[i].bf = take(l.O);
+            L[i].dT = take(wsz); L[i].dw1p = take((size_t)9 * 2 * l.C * l.C);
+        }
         Cn = l.O / (l.s * l.s); H = l.H * l.s; W = l.W * l.s;
         const size_t asz = (size_t)Cn * H * W;
         size_t s1;
@@ -131,6 +137,7 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
     if (s3 > scratch) scratch = s3;
     float *scr = take(scratch);
     float *cur = take(16);
+    float *mtab = d->erb ? take(orn_merge_group_bytes() / 4) : nullptr;
     if (e) {
         e->pre1 = pre1; e->h1 = h1; e->pre2 = pre2; e->h2 = h2; e->dh2 = dh2;
         e->img = img; e->dimg = dimg; e->stats = stats; e->loss_ws = loss_ws; e->scratch = scr;
@@ -138,6 +145,7 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
         for (int i = 0; i < d->n_layers; ++i) e->L[i] = L[i];
         e->Hout = H; e->Wout = W; e->Cn_last = Cn;
         e->ff = ff; e->dxn = dxn;
+        e->merge_tables = mtab;
     }
     return off * 4;
 }
@@ -179,6 +187,23 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
             e->L[i].wf = params + d->layer[i].w3x3;
             e->L[i].bf = params + d->layer[i].b3x3;
         }
+    else {
+        OrnMergeLayer ml[ORN_MAX_LAYERS];
+        for (int i = 0; i < d->n_layers; ++i) {
+            const orn_layer_desc &l = d->layer[i];
+            OrnMergeLayer &m = ml[i];
+            m.C = l.C; m.O = l.O;
+            m.w3x3 = params + l.w3x3; m.w3x1 = params + l.w3x1; m.w1x3 = params + l.w1x3;
+            m.w1 = params + l.w1; m.w2 = params + l.w2; m.w3 = params + l.w3;
+            m.T = e->L[i].T; m.wf = e->L[i].wf;
+            m.g = grads ? grads + l.w3x3 : nullptr;
+            m.dT = e->L[i].dT; m.dw1p = e->L[i].dw1p;
+            m.dw2 = grads ? grads + l.w2 : nullptr; m.dw3 = grads ? grads + l.w3 : nullptr;
+        }
+        const int rc = orn_merge_groups_build(e->merge_tables, d->n_layers, ml);
+        if (rc != 0) { delete e; return rc; }
+        for (int k = 0; k < 4; ++k) e->merge_tiles[k] = orn_merge_group_tiles(k, d->n_layers, ml);
+    }
     *out = e;
     return 0;
 }
@@ -240,12 +265,18 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
     ORN_TRY(orn_launch_linear_silu(e->h1, nullptr, 0, P + d.stem_w1, P + d.stem_b1, 1, d.stem_dim, Nout, e->pre2, e->h2, st));
     const float *x = e->h2;
     const int nl = d.n_layers, ff = e->ff;
+    if (d.erb) {
+        // online re-parameterisation of every layer (model.py:534): weights only, so all layers up front
+        ORN_TRY(orn_launch_merge_group(e->merge_tables, 0, e->merge_tiles[0], st));
+        ORN_TRY(orn_launch_merge_group(e->merge_tables, 1, e->merge_tiles[1], st));
+        for (int i = 0; i < nl; ++i) {
+            const orn_layer_desc &l = d.layer[i];
+            ORN_TRY(orn_launch_merge_bias(P + l.b3x3, P + l.b1x3, P + l.b3x1, l.O, e->L[i].bf, st));
+        }
+    }
     for (int i = 0; i < nl; ++i) {
         const orn_layer_desc &l = d.layer[i];
         LayerBuf &b = e->L[i];
-        if (d.erb)
-            ORN_TRY(orn_launch_merge_fwd(P + l.w3x3, P + l.b3x3, P + l.w3x1, P + l.b3x1, P + l.w1x3, P + l.b1x3, P + l.w1,
-                                         P + l.w2, P + l.w3, l.C, l.O, b.T, b.wf, b.bf, st));
         if (i < ff) {
             ORN_TRY(orn_launch_conv3x3_f32(x, b.wf, b.bf, 1, l.C, l.O, l.H, l.W, l.s, 1, keep_z ? b.z : nullptr, b.a, st, nullptr));
             x = b.a;
@@ -315,10 +346,16 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
             }
         } else
         ORN_TRY(orn_launch_conv_bwd_f32(x, b.wf, b.z, b.da, 1, l.C, l.O, l.H, l.W, l.s, dx, G + l.w3x3, G + l.b3x3, e->scratch, st));
-        if (d.erb)
-            ORN_TRY(orn_launch_merge_bwd(G + l.w3x3, G + l.b3x3, P + l.w1, P + l.w2, P + l.w3, b.T, l.C, l.O, G + l.w3x3,
-                                         G + l.b3x3, G + l.w3x1, G + l.b3x1, G + l.w1x3, G + l.b1x3, G + l.w1, G + l.w2,
-                                         G + l.w3, e->scratch, st));
+    }
+    if (d.erb) {
+        // merge backward of every layer (closed forms): dW3 & dT, then dW2 & dW1, then the slices
+        ORN_TRY(orn_launch_merge_group(e->merge_tables, 2, e->merge_tiles[2], st));
+        ORN_TRY(orn_launch_merge_group(e->merge_tables, 3, e->merge_tiles[3], st));
+        for (int i = 0; i < nl; ++i) {
+            const orn_layer_desc &l = d.layer[i];
+            ORN_TRY(orn_launch_merge_bwd_tail(G + l.w3x3, G + l.b3x3, l.C, l.O, G + l.w3x3, G + l.b3x3, G + l.w3x1, G + l.b3x1,
+                                              G + l.w1x3, G + l.b1x3, e->L[i].dw1p, G + l.w1, st));
+        }
     }
     ORN_TRY(orn_launch_stem_bwd(embeds, fidx, d.embed_len, P + d.stem_w1, e->pre1, e->h1, e->pre2, e->dh2, 1, d.embed_len,
                                 d.stem_dim, Nout, G + d.stem_w0, G + d.stem_b0, G + d.stem_w1, G + d.stem_b1, e->scratch, st));

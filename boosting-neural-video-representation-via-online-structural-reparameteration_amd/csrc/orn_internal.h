@@ -24,6 +24,22 @@ int orn_launch_merge_bwd(const float *g, const float *dbf, const float *w1, cons
                          const float *T, int C, int O, float *d3x3, float *db3x3, float *d3x1, float *db3x1,
                          float *d1x3, float *db1x3, float *dw1, float *dw2, float *dw3, float *ws, hipStream_t st);
 
+// grouped merge (engine): all ERB layers per launch
+struct OrnMergeLayer {
+    int C, O;
+    const float *w3x3, *w3x1, *w1x3, *w1, *w2, *w3;   // parameters
+    float *T, *wf;                                    // forward products
+    const float *g;                                   // dL/dWf (in the gradient arena)
+    float *dT, *dw1p, *dw2, *dw3;                     // backward scratch / outputs
+};
+size_t orn_merge_group_bytes();
+int orn_merge_groups_build(void *dev_tables, int n_layers, const OrnMergeLayer *L);
+int orn_merge_group_tiles(int which, int n_layers, const OrnMergeLayer *L);
+int orn_launch_merge_group(const void *dev_tables, int which, int tiles, hipStream_t st);
+int orn_launch_merge_bias(const float *b3x3, const float *b1x3, const float *b3x1, int O, float *bf, hipStream_t st);
+int orn_launch_merge_bwd_tail(const float *g, const float *dbf, int C, int O, float *d3x3, float *db3x3, float *d3x1,
+                              float *db3x1, float *d1x3, float *db1x3, const float *dw1p, float *dw1, hipStream_t st);
+
 // orn_conv_f32.hip
 int orn_launch_conv3x3_f32(const float *x, const float *w, const float *bias, int B, int C, int O, int H, int W,
                            int s, int epi, float *z, float *out, hipStream_t st, float *split_ws);

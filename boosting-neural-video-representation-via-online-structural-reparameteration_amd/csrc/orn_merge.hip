@@ -4,7 +4,7 @@
 // operands (a few MB, L2/MALL resident).  They run on one generic strided/batched fp32 GEMM whose
 // every output element is a SINGLE k-ordered fmaf chain starting from +0.0f -- the summation order
 // oracle/merge_ref.c specifies -- so the forward is bit-exact against the CPU oracle.
-#include "orn_common.h"
+#include "orn_internal.h"
 
 struct GemmP {
     const float *A, *B;
@@ -33,17 +33,17 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define GLDA (GK + 1)
 #define GLDB (GT + 4)
 
-__global__ void __launch_bounds__(256) k_gemm_f32(GemmP p)
+__device__ __forceinline__ void gemm_body(const GemmP &p, int bx, int by, int bz)
 {
     __shared__ float As[2][GT][GLDA];
     __shared__ float Bs[2][GK][GLDB];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
-    const float *A = p.A + (long)blockIdx.z * p.ba;
-    const float *B = p.B + (long)blockIdx.z * p.bb;
-    float *C = p.C + (long)blockIdx.z * p.bc;
+    const int m0 = by * GT, n0 = bx * GT;
+    const float *A = p.A + (long)bz * p.ba;
+    const float *B = p.B + (long)bz * p.bb;
+    float *C = p.C + (long)bz * p.bc;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -111,10 +111,38 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmP p)
     }
 }
 
-static int launch_gemm(GemmP p, int batch, hipStream_t st, const char *name)
+__global__ void __launch_bounds__(256) k_gemm_f32(GemmP p) { gemm_body(p, blockIdx.x, blockIdx.y, blockIdx.z); }
+
+// Grouped form: several independent problems in one launch (the engine merges all layers at once so
+// the small per-layer GEMMs fill the chip together).  The table lives in device memory.
+#define GEMM_MAXP 16
+struct GemmGroup {
+    int n;
+    int tile_start[GEMM_MAXP + 1];
+    GemmP prob[GEMM_MAXP];
+};
+
+__global__ void __launch_bounds__(256) k_gemm_f32_grouped(const GemmGroup *__restrict__ g)
+{
+    const int bid = blockIdx.x;
+    int pi = 0;
+    while (pi + 1 < g->n && bid >= g->tile_start[pi + 1]) ++pi;
+    const GemmP p = g->prob[pi];
+    const int local = bid - g->tile_start[pi];
+    const int tn = (p.N + GT - 1) / GT, tm = (p.M + GT - 1) / GT;
+    const int bz = local / (tn * tm), rem = local - bz * tn * tm;
+    gemm_body(p, rem % tn, rem / tn, bz);
+}
+
+static void finish_gemm(GemmP &p)
 {
     p.a_kfast = (labs(p.sak) <= labs(p.sam)) ? 1 : 0;
     p.b_nfast = (labs(p.sbn) <= labs(p.sbk)) ? 1 : 0;
+}
+
+static int launch_gemm(GemmP p, int batch, hipStream_t st, const char *name)
+{
+    finish_gemm(p);
     hipLaunchKernelGGL(k_gemm_f32, dim3(orn_cdiv(p.N, GT), orn_cdiv(p.M, GT), batch), dim3(256), 0, st, p);
     ORN_LAUNCH_CHECK(name);
     return 0;
@@ -127,25 +155,35 @@ __global__ void k_bias3(const float *__restrict__ a, const float *__restrict__ b
     if (i < n) out[i] = a[i] + (b[i] + c[i]);     // b3x3 + (b1x3 + b3x1), model.py:476,496
 }
 
-int orn_launch_merge_fwd(const float *w3x3, const float *b3x3, const float *w3x1, const float *b3x1,
-                         const float *w1x3, const float *b1x3, const float *w1, const float *w2, const float *w3,
-                         int C, int O, float *T, float *wf, float *bf, hipStream_t st)
+// T[m,c,ij] = sum_k W2[m,k,ij] * W1[k,c]     (9 batches over ij)
+static GemmP prob_T(const float *w1, const float *w2, int C, int O, float *T)
 {
     const int K2 = 2 * C;
     GemmP p = {};
-    // T[m,c,ij] = sum_k W2[m,k,ij] * W1[k,c]     (9 batches over ij)
     p.A = w2; p.B = w1; p.C = T;
     p.M = O; p.N = C; p.K = K2;
     p.sam = (long)K2 * 9; p.sak = 9; p.sbk = C; p.sbn = 1; p.scm = (long)C * 9; p.scn = 9;
     p.ba = 1; p.bb = 0; p.bc = 1; p.epi = 0;
-    ORN_TRY(launch_gemm(p, 9, st, "merge_T"));
-    // Wf[o,e] = (W3x3 + (P13 + P31))[o,e] + sum_m W3[o,m] * T[m,e]
+    return p;
+}
+// Wf[o,e] = (W3x3 + (P13 + P31))[o,e] + sum_m W3[o,m] * T[m,e]
+static GemmP prob_S(const float *w3x3, const float *w3x1, const float *w1x3, const float *w3, const float *T, int C, int O,
+                    float *wf)
+{
     GemmP q = {};
     q.A = w3; q.B = T; q.C = wf;
     q.M = O; q.N = C * 9; q.K = O;
     q.sam = O; q.sak = 1; q.sbk = (long)C * 9; q.sbn = 1; q.scm = (long)C * 9; q.scn = 1;
     q.epi = 1; q.w3x3 = w3x3; q.w1x3 = w1x3; q.w3x1 = w3x1; q.Cch = C;
-    ORN_TRY(launch_gemm(q, 1, st, "merge_S"));
+    return q;
+}
+
+int orn_launch_merge_fwd(const float *w3x3, const float *b3x3, const float *w3x1, const float *b3x1,
+                         const float *w1x3, const float *b1x3, const float *w1, const float *w2, const float *w3,
+                         int C, int O, float *T, float *wf, float *bf, hipStream_t st)
+{
+    ORN_TRY(launch_gemm(prob_T(w1, w2, C, O, T), 9, st, "merge_T"));
+    ORN_TRY(launch_gemm(prob_S(w3x3, w3x1, w1x3, w3, T, C, O, wf), 1, st, "merge_S"));
     hipLaunchKernelGGL(k_bias3, dim3(orn_cdiv(O, 256)), dim3(256), 0, st, b3x3, b1x3, b3x1, O, bf);
     ORN_LAUNCH_CHECK("merge_bias");
     return 0;
@@ -192,6 +230,47 @@ __global__ void k_merge_bwd_slices(const float *__restrict__ g, const float *__r
     }
 }
 
+// dW3[o,m] = sum_e G[o,e] * T[m,e]
+static GemmP prob_dW3(const float *g, const float *T, int C, int O, float *dw3)
+{
+    const long n = (long)C * 9;
+    GemmP p = {};
+    p.A = g; p.B = T; p.C = dw3; p.M = O; p.N = O; p.K = (int)n;
+    p.sam = n; p.sak = 1; p.sbk = 1; p.sbn = n; p.scm = O; p.scn = 1;
+    return p;
+}
+// dT[m,e] = sum_o W3[o,m] * G[o,e]
+static GemmP prob_dT(const float *g, const float *w3, int C, int O, float *dT)
+{
+    const long n = (long)C * 9;
+    GemmP p = {};
+    p.A = w3; p.B = g; p.C = dT; p.M = O; p.N = (int)n; p.K = O;
+    p.sam = 1; p.sak = O; p.sbk = n; p.sbn = 1; p.scm = n; p.scn = 1;
+    return p;
+}
+// dW2[m,k,ij] = sum_c dT[m,c,ij] * W1[k,c]        (9 batches)
+static GemmP prob_dW2(const float *dT, const float *w1, int C, int O, float *dw2)
+{
+    const long n = (long)C * 9;
+    const int K2 = 2 * C;
+    GemmP p = {};
+    p.A = dT; p.B = w1; p.C = dw2; p.M = O; p.N = K2; p.K = C;
+    p.sam = n; p.sak = 9; p.sbk = 1; p.sbn = C; p.scm = (long)K2 * 9; p.scn = 9;
+    p.ba = 1; p.bb = 0; p.bc = 1;
+    return p;
+}
+// dW1[k,c] = sum_ij sum_m W2[m,k,ij] * dT[m,c,ij]  (9 batched partials, then a fixed-order sum)
+static GemmP prob_dW1p(const float *w2, const float *dT, int C, int O, float *dw1p)
+{
+    const long n = (long)C * 9;
+    const int K2 = 2 * C;
+    GemmP p = {};
+    p.A = w2; p.B = dT; p.C = dw1p; p.M = K2; p.N = C; p.K = O;
+    p.sam = 9; p.sak = (long)K2 * 9; p.sbk = n; p.sbn = 9; p.scm = C; p.scn = 1;
+    p.ba = 1; p.bb = 1; p.bc = (long)K2 * C;
+    return p;
+}
+
 extern "C" size_t orn_erb_merge_bwd_ws_bytes(int C, int O)
 {
     // dT [O*C*9] + dW1 partials [9][2C*C]
@@ -209,33 +288,11 @@ int orn_launch_merge_bwd(const float *g, const float *dbf, const float *w1, cons
     hipLaunchKernelGGL(k_merge_bwd_slices, dim3(orn_cdiv((long)O * C, 256)), dim3(256), 0, st, g, dbf, (long)O * C, O,
                        d3x3, db3x3, d3x1, db3x1, d1x3, db1x3);
     ORN_LAUNCH_CHECK("merge_bwd_slices");
-    {   // dW3[o,m] = sum_e G[o,e] * T[m,e]
-        GemmP p = {};
-        p.A = g; p.B = T; p.C = dw3; p.M = O; p.N = O; p.K = (int)n;
-        p.sam = n; p.sak = 1; p.sbk = 1; p.sbn = n; p.scm = O; p.scn = 1;
-        ORN_TRY(launch_gemm(p, 1, st, "merge_dW3"));
-    }
-    {   // dT[m,e] = sum_o W3[o,m] * G[o,e]
-        GemmP p = {};
-        p.A = w3; p.B = g; p.C = dT; p.M = O; p.N = (int)n; p.K = O;
-        p.sam = 1; p.sak = O; p.sbk = n; p.sbn = 1; p.scm = n; p.scn = 1;
-        ORN_TRY(launch_gemm(p, 1, st, "merge_dT"));
-    }
-    {   // dW2[m,k,ij] = sum_c dT[m,c,ij] * W1[k,c]        (9 batches)
-        GemmP p = {};
-        p.A = dT; p.B = w1; p.C = dw2; p.M = O; p.N = K2; p.K = C;
-        p.sam = n; p.sak = 9; p.sbk = 1; p.sbn = C; p.scm = (long)K2 * 9; p.scn = 9;
-        p.ba = 1; p.bb = 0; p.bc = 1;
-        ORN_TRY(launch_gemm(p, 9, st, "merge_dW2"));
-    }
-    {   // dW1[k,c] = sum_ij sum_m W2[m,k,ij] * dT[m,c,ij]  (9 batched partials, then fixed-order sum)
-        GemmP p = {};
-        p.A = w2; p.B = dT; p.C = dw1p; p.M = K2; p.N = C; p.K = O;
-        p.sam = 9; p.sak = (long)K2 * 9; p.sbk = n; p.sbn = 9; p.scm = C; p.scn = 1;
-        p.ba = 1; p.bb = 1; p.bc = (long)K2 * C;
-        ORN_TRY(launch_gemm(p, 9, st, "merge_dW1"));
-        ORN_TRY(orn_launch_reduce_rows(dw1p, 9, (size_t)K2 * C, (size_t)K2 * C, dw1, st));
-    }
+    ORN_TRY(launch_gemm(prob_dW3(g, T, C, O, dw3), 1, st, "merge_dW3"));
+    ORN_TRY(launch_gemm(prob_dT(g, w3, C, O, dT), 1, st, "merge_dT"));
+    ORN_TRY(launch_gemm(prob_dW2(dT, w1, C, O, dw2), 9, st, "merge_dW2"));
+    ORN_TRY(launch_gemm(prob_dW1p(w2, dT, C, O, dw1p), 9, st, "merge_dW1"));
+    ORN_TRY(orn_launch_reduce_rows(dw1p, 9, (size_t)K2 * C, (size_t)K2 * C, dw1, st));
     return 0;
 }
 
@@ -253,4 +310,77 @@ extern "C" int orn_erb_merge_bwd(const float *g, const float *dbf, const float *
     }
     return orn_launch_merge_bwd(g, dbf, w1, w2, w3, T, C, O, d3x3, db3x3, d3x1, db3x1, d1x3, db1x3, dw1, dw2, dw3,
                                 (float *)ws, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Grouped merge for the engine: all ERB layers in four GEMM launches per step.
+// ------------------------------------------------------------------------------------------------
+static void group_add(GemmGroup &g, GemmP p, int batch)
+{
+    finish_gemm(p);
+    const int tiles = orn_cdiv(p.N, GT) * orn_cdiv(p.M, GT) * batch;
+    g.prob[g.n] = p;
+    g.tile_start[g.n + 1] = g.tile_start[g.n] + tiles;
+    ++g.n;
+}
+
+size_t orn_merge_group_bytes() { return orn_align(4 * sizeof(GemmGroup)); }
+
+// Builds the four device-resident problem tables (host side, at engine creation; synchronous copy).
+int orn_merge_groups_build(void *dev_tables, int n_layers, const OrnMergeLayer *L)
+{
+    ORN_REQUIRE(2 * n_layers <= GEMM_MAXP, "merge groups: too many layers");
+    GemmGroup *h = new GemmGroup[4]();
+    for (int i = 0; i < n_layers; ++i) {
+        const OrnMergeLayer &l = L[i];
+        group_add(h[0], prob_T(l.w1, l.w2, l.C, l.O, l.T), 9);
+        group_add(h[1], prob_S(l.w3x3, l.w3x1, l.w1x3, l.w3, l.T, l.C, l.O, l.wf), 1);
+        group_add(h[2], prob_dW3(l.g, l.T, l.C, l.O, l.dw3), 1);
+        group_add(h[2], prob_dT(l.g, l.w3, l.C, l.O, l.dT), 1);
+        group_add(h[3], prob_dW2(l.dT, l.w1, l.C, l.O, l.dw2), 9);
+        group_add(h[3], prob_dW1p(l.w2, l.dT, l.C, l.O, l.dw1p), 9);
+    }
+    hipError_t e = hipMemcpy(dev_tables, h, 4 * sizeof(GemmGroup), hipMemcpyHostToDevice);
+    delete[] h;
+    if (e != hipSuccess) { orn_set_error("merge groups: hipMemcpy failed: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
+int orn_merge_group_tiles(int which, int n_layers, const OrnMergeLayer *L)
+{
+    int t = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        const int C = L[i].C, O = L[i].O, n = C * 9, K2 = 2 * C;
+        switch (which) {
+        case 0: t += orn_cdiv(C, GT) * orn_cdiv(O, GT) * 9; break;
+        case 1: t += orn_cdiv(n, GT) * orn_cdiv(O, GT); break;
+        case 2: t += orn_cdiv(O, GT) * orn_cdiv(O, GT) + orn_cdiv(n, GT) * orn_cdiv(O, GT); break;
+        default: t += orn_cdiv(K2, GT) * orn_cdiv(O, GT) * 9 + orn_cdiv(C, GT) * orn_cdiv(K2, GT) * 9; break;
+        }
+    }
+    return t;
+}
+
+int orn_launch_merge_group(const void *dev_tables, int which, int tiles, hipStream_t st)
+{
+    const GemmGroup *g = (const GemmGroup *)dev_tables + which;
+    hipLaunchKernelGGL(k_gemm_f32_grouped, dim3(tiles), dim3(256), 0, st, g);
+    ORN_LAUNCH_CHECK("merge_group");
+    return 0;
+}
+
+int orn_launch_merge_bias(const float *b3x3, const float *b1x3, const float *b3x1, int O, float *bf, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_bias3, dim3(orn_cdiv(O, 256)), dim3(256), 0, st, b3x3, b1x3, b3x1, O, bf);
+    ORN_LAUNCH_CHECK("merge_bias");
+    return 0;
+}
+
+int orn_launch_merge_bwd_tail(const float *g, const float *dbf, int C, int O, float *d3x3, float *db3x3, float *d3x1,
+                              float *db3x1, float *d1x3, float *db1x3, const float *dw1p, float *dw1, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_merge_bwd_slices, dim3(orn_cdiv((long)O * C, 256)), dim3(256), 0, st, g, dbf, (long)O * C, O, d3x3,
+                       db3x3, d3x1, db3x1, d1x3, db1x3);
+    ORN_LAUNCH_CHECK("merge_bwd_slices");
+    return orn_launch_reduce_rows(dw1p, 9, (size_t)2 * C * C, (size_t)2 * C * C, dw1, st);
 }
