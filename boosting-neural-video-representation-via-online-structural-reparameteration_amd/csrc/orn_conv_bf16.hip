@@ -765,7 +765,7 @@ k_head_bwd_nhwc_bf16(const h16 *__restrict__ z, const float *__restrict__ w, con
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float zz = (float)v[e];
-                const float sg = 1.0f / (1.0f + __expf(-zz));
+                const float sg = orn_sigmoid(zz);
                 const float a = zz * sg;
                 const float da = fmaf(sw[2 * C + c0 + e], du[2], fmaf(sw[C + c0 + e], du[1], sw[c0 + e] * du[0]));
                 o8[e] = (h16)(da * (sg * (1.0f + zz * (1.0f - sg))));
@@ -815,7 +815,7 @@ __global__ void k_head_bf16_finish(const float *__restrict__ red, int C, float g
     else if (i < 3 * C + 3) db[i - 3 * C] = red[i] * gscale;
 }
 
-#define HB_BLOCKS 256
+#define HB_BLOCKS 512
 
 int orn_launch_head_fwd_bf16(const h16 *z, const float *w, const float *b, int C, size_t HW, int sigmoid, float *out, hipStream_t st)
 {

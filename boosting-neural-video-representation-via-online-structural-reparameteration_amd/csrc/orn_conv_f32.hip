@@ -66,21 +66,38 @@ __global__ void __launch_bounds__(256) k_conv3x3_f32(ConvP p)
 
     const int r0 = wave * 2;                   // first of the wave's two output rows (tile-local)
     for (int c0 = c_begin; c0 < c_end; c0 += CV_CC) {
-        // ---- stage the input patch (zero padded) and the weight tile --------------------------
-        for (int idx = t; idx < CV_CC * CV_XH * CV_XW; idx += 256) {
+        // ---- stage the input patch (zero padded) and the weight tile: every global load is issued
+        //      before the first LDS write, so one memory latency is exposed per chunk instead of ~30
+        constexpr int XN = (CV_CC * CV_XH * CV_XW + 255) / 256, WN = (CV_BO * CV_CC * 9) / 256;
+        float xr[XN], wr[WN];
+#pragma unroll
+        for (int it = 0; it < XN; ++it) {
+            const int idx = t + it * 256;
             const int c = idx / (CV_XH * CV_XW);
             const int rem = idx - c * (CV_XH * CV_XW);
             const int r = rem / CV_XW, xx = rem - r * CV_XW;
             const int gh = h0 + r - 1, gw = w0 + xx - 1, gc = c0 + c;
-            float v = 0.f;
-            if (gc < c_end && gh >= 0 && gh < H && gw >= 0 && gw < W) v = xb[((size_t)gc * H + gh) * W + gw];
-            (&Xs[0][0][0])[idx] = v;
+            xr[it] = 0.f;
+            if (idx < CV_CC * CV_XH * CV_XW && gc < c_end && gh >= 0 && gh < H && gw >= 0 && gw < W)
+                xr[it] = xb[((size_t)gc * H + gh) * W + gw];
         }
-        for (int idx = t; idx < CV_BO * CV_CC * 9; idx += 256) {
+#pragma unroll
+        for (int it = 0; it < WN; ++it) {
+            const int idx = t + it * 256;
             const int o = idx / (CV_CC * 9), kk = idx - o * (CV_CC * 9);
-            float v = 0.f;
-            if (o0 + o < p.O && c0 * 9 + kk < c_end * 9) v = p.w[(size_t)(o0 + o) * C * 9 + (size_t)c0 * 9 + kk];
-            Ws[o][kk] = v;
+            wr[it] = 0.f;
+            if (o0 + o < p.O && c0 * 9 + kk < c_end * 9) wr[it] = p.w[(size_t)(o0 + o) * C * 9 + (size_t)c0 * 9 + kk];
+        }
+#pragma unroll
+        for (int it = 0; it < XN; ++it) {
+            const int idx = t + it * 256;
+            if (idx < CV_CC * CV_XH * CV_XW) (&Xs[0][0][0])[idx] = xr[it];
+        }
+#pragma unroll
+        for (int it = 0; it < WN; ++it) {
+            const int idx = t + it * 256;
+            const int o = idx / (CV_CC * 9), kk = idx - o * (CV_CC * 9);
+            Ws[o][kk] = wr[it];
         }
         __syncthreads();
         // ---- 36 MFMA k-steps ---------------------------------------------------------------------
@@ -292,22 +309,38 @@ __global__ void __launch_bounds__(256) k_wgrad_f32(WgradP p)
         const int h0 = th * WG_TH, w0 = tw * WG_TW;
         const float *xb = p.x + (size_t)b * C * H * W;
         const float *dyb = p.dy + (size_t)b * p.O * H * W;
-        for (int idx = t; idx < WG_BO * WG_NPX; idx += 256) {
+        constexpr int DN = (WG_BO * WG_NPX) / 256, XN = (WG_MAXC * WG_XH * WG_XW + 255) / 256;
+        float dr[DN], xr[XN];
+#pragma unroll
+        for (int it = 0; it < DN; ++it) {
+            const int idx = t + it * 256;
             const int o = idx / WG_NPX, px = idx - o * WG_NPX;
             const int r = px / WG_TW, xx = px - r * WG_TW;
             const int gh = h0 + r, gw = w0 + xx;
-            float v = 0.f;
-            if (o0 + o < p.O && gh < H && gw < W) v = dyb[((size_t)(o0 + o) * H + gh) * W + gw];
-            Ds[o][px] = v;
+            dr[it] = 0.f;
+            if (o0 + o < p.O && gh < H && gw < W) dr[it] = dyb[((size_t)(o0 + o) * H + gh) * W + gw];
         }
-        for (int idx = t; idx < WG_MAXC * WG_XH * WG_XW; idx += 256) {
+#pragma unroll
+        for (int it = 0; it < XN; ++it) {
+            const int idx = t + it * 256;
             const int c = idx / (WG_XH * WG_XW);
             const int rem2 = idx - c * (WG_XH * WG_XW);
             const int r = rem2 / WG_XW, xx = rem2 - r * WG_XW;
             const int gh = h0 + r - 1, gw = w0 + xx - 1, gc = c_lo + c;
-            float v = 0.f;
-            if (gc < C && gh >= 0 && gh < H && gw >= 0 && gw < W) v = xb[((size_t)gc * H + gh) * W + gw];
-            (&Xs[0][0][0])[idx] = v;
+            xr[it] = 0.f;
+            if (idx < WG_MAXC * WG_XH * WG_XW && gc < C && gh >= 0 && gh < H && gw >= 0 && gw < W)
+                xr[it] = xb[((size_t)gc * H + gh) * W + gw];
+        }
+#pragma unroll
+        for (int it = 0; it < DN; ++it) {
+            const int idx = t + it * 256;
+            const int o = idx / WG_NPX, px = idx - o * WG_NPX;
+            Ds[o][px] = dr[it];
+        }
+#pragma unroll
+        for (int it = 0; it < XN; ++it) {
+            const int idx = t + it * 256;
+            if (idx < WG_MAXC * WG_XH * WG_XW) (&Xs[0][0][0])[idx] = xr[it];
         }
         __syncthreads();
         const float *dsp = &Ds[0][0] + doff;

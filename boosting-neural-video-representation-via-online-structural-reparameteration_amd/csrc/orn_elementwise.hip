@@ -40,9 +40,35 @@ __global__ void k_reduce_rows(const float *__restrict__ in, int rows, size_t ld,
     out[j] = acc;
 }
 
+// Many rows, few columns: 32 columns x 8 row-lanes per block; each lane sums rows r = lane (mod 8) in
+// ascending order, then the 8 lane sums are added in fixed order through LDS.  Deterministic.
+__global__ void __launch_bounds__(256) k_reduce_rows_tall(const float *__restrict__ in, int rows, size_t ld, size_t n,
+                                                         float *__restrict__ out)
+{
+    __shared__ float sm[8][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const size_t j = (size_t)blockIdx.x * 32 + cx;
+    float acc = 0.f;
+    if (j < n)
+        for (int i = ry; i < rows; i += 8) acc += in[(size_t)i * ld + j];
+    sm[ry][cx] = acc;
+    __syncthreads();
+    if (ry == 0 && j < n) {
+        float r = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r += sm[k][cx];
+        out[j] = r;
+    }
+}
+
 int orn_launch_reduce_rows(const float *in, int rows, size_t ld, size_t n, float *out, hipStream_t st)
 {
     if (n == 0) return 0;
+    if (rows >= 32 && n <= 65536) {
+        hipLaunchKernelGGL(k_reduce_rows_tall, dim3(orn_cdiv((long)n, 32)), dim3(256), 0, st, in, rows, ld, n, out);
+        ORN_LAUNCH_CHECK("reduce_rows_tall");
+        return 0;
+    }
     hipLaunchKernelGGL(k_reduce_rows, dim3(orn_cdiv((long)n, 256)), dim3(256), 0, st, in, rows, ld, n, out);
     ORN_LAUNCH_CHECK("reduce_rows");
     return 0;
