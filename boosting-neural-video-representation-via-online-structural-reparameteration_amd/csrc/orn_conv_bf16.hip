@@ -447,21 +447,38 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p)
         const int th = kt / p.tiles_w, tw = kt - th * p.tiles_w;
         const int h0 = th * WB_TH, w0 = tw * WB_TW;
         __syncthreads();
-        for (int idx = t; idx < WB_NPX * 16; idx += 256) {
+        // all global loads of the tile in flight before the first LDS write (one exposed latency per tile)
+        constexpr int DYN = (WB_NPX * 16) / 256, XN = (WB_TH * WB_XW * 12 + 255) / 256;
+        u32x4 dv[DYN], xv[XN];
+#pragma unroll
+        for (int it = 0; it < DYN; ++it) {
+            const int idx = t + it * 256;
             const int px = idx >> 4, ch = idx & 15;
             const int r = px / WB_TW, c = px - r * WB_TW;
             const int gh = h0 + r, gw = w0 + c;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (gh < H && gw < W) v = *reinterpret_cast<const uint4 *>(p.dypad + ((size_t)(gh + 1) * (W + 2) + (gw + 1)) * O + o0 + ch * 8);
-            *reinterpret_cast<uint4 *>(dys + px * WB_DYB + ch * 16) = v;
+            dv[it] = u32x4{0u, 0u, 0u, 0u};
+            if (gh < H && gw < W) dv[it] = *reinterpret_cast<const u32x4 *>(p.dypad + ((size_t)(gh + 1) * (W + 2) + (gw + 1)) * O + o0 + ch * 8);
         }
-        for (int idx = t; idx < WB_TH * WB_XW * 12; idx += 256) {
+#pragma unroll
+        for (int it = 0; it < XN; ++it) {
+            const int idx = t + it * 256;
             const int px = idx / 12, ch = idx - px * 12;
             const int r = px / WB_XW, c = px - r * WB_XW;
             const int gh = h0 + r + ti, gw = w0 + c;          // padded coords of x
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (gh < H + 2 && gw < W + 2) v = *reinterpret_cast<const uint4 *>(p.xpad + ((size_t)gh * (W + 2) + gw) * 96 + ch * 8);
-            *reinterpret_cast<uint4 *>(xs + px * WB_XB + ch * 16) = v;
+            xv[it] = u32x4{0u, 0u, 0u, 0u};
+            if (idx < WB_TH * WB_XW * 12 && gh < H + 2 && gw < W + 2)
+                xv[it] = *reinterpret_cast<const u32x4 *>(p.xpad + ((size_t)gh * (W + 2) + gw) * 96 + ch * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < DYN; ++it) {
+            const int idx = t + it * 256;
+            *reinterpret_cast<u32x4 *>(dys + (idx >> 4) * WB_DYB + (idx & 15) * 16) = dv[it];
+        }
+#pragma unroll
+        for (int it = 0; it < XN; ++it) {
+            const int idx = t + it * 256;
+            const int px = idx / 12, ch = idx - px * 12;
+            if (idx < WB_TH * WB_XW * 12) *reinterpret_cast<u32x4 *>(xs + px * WB_XB + ch * 16) = xv[it];
         }
         __syncthreads();
 #pragma unroll

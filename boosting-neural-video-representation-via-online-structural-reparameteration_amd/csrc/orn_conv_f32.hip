@@ -39,46 +39,53 @@ struct ConvP {
     int nsplit, c_per_split;   // EPI_PLAIN: input channels split over blockIdx.z (partial slabs, reduced afterwards)
 };
 
-template <int EPI>
+// SMALL = 1: 2-row tiles (64 pixels), each wave one 32x32 block -- 4x more work-groups for the small early layers,
+// whose cost is latency, not throughput.
+template <int EPI, int SMALL>
 __global__ void __launch_bounds__(256) k_conv3x3_f32(ConvP p)
 {
-    __shared__ float Xs[CV_CC][CV_XH][CV_XW];
+    constexpr int TH = SMALL ? 2 : CV_TH;
+    constexpr int XH = TH + 2;
+    constexpr int RW = SMALL ? 1 : 2;          // rows per wave
+    constexpr int OBW = SMALL ? 1 : 2;         // 32-channel blocks per wave
+    __shared__ float Xs[CV_CC][XH][CV_XW];
     __shared__ float Ws[CV_BO][CV_WLD];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     const int tile = blockIdx.x;
     const int tw = tile % p.tiles_w, th = tile / p.tiles_w;
-    const int h0 = th * CV_TH, w0 = tw * CV_TW;
+    const int h0 = th * TH, w0 = tw * CV_TW;
     const int o0 = blockIdx.y * CV_BO;
     const int b = blockIdx.z / p.nsplit, split = blockIdx.z - b * p.nsplit;
     const int C = p.C, H = p.H, W = p.W;
     const float *xb = p.x + (size_t)b * C * H * W;
     const int c_begin = split * p.c_per_split, c_end = min(C, c_begin + p.c_per_split);
 
-    f32x16 acc[2][2];
+    f32x16 acc[OBW][RW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < OBW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < RW; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int r0 = wave * 2;                   // first of the wave's two output rows (tile-local)
+    const int r0 = SMALL ? (wave >> 1) : wave * 2;     // first output row of the wave (tile-local)
+    const int ob0 = SMALL ? (wave & 1) : 0;            // first 32-channel block of the wave
     for (int c0 = c_begin; c0 < c_end; c0 += CV_CC) {
         // ---- stage the input patch (zero padded) and the weight tile: every global load is issued
         //      before the first LDS write, so one memory latency is exposed per chunk instead of ~30
-        constexpr int XN = (CV_CC * CV_XH * CV_XW + 255) / 256, WN = (CV_BO * CV_CC * 9) / 256;
+        constexpr int XN = (CV_CC * XH * CV_XW + 255) / 256, WN = (CV_BO * CV_CC * 9) / 256;
         float xr[XN], wr[WN];
 #pragma unroll
         for (int it = 0; it < XN; ++it) {
             const int idx = t + it * 256;
-            const int c = idx / (CV_XH * CV_XW);
-            const int rem = idx - c * (CV_XH * CV_XW);
+            const int c = idx / (XH * CV_XW);
+            const int rem = idx - c * (XH * CV_XW);
             const int r = rem / CV_XW, xx = rem - r * CV_XW;
             const int gh = h0 + r - 1, gw = w0 + xx - 1, gc = c0 + c;
             xr[it] = 0.f;
-            if (idx < CV_CC * CV_XH * CV_XW && gc < c_end && gh >= 0 && gh < H && gw >= 0 && gw < W)
+            if (idx < CV_CC * XH * CV_XW && gc < c_end && gh >= 0 && gh < H && gw >= 0 && gw < W)
                 xr[it] = xb[((size_t)gc * H + gh) * W + gw];
         }
 #pragma unroll
@@ -91,7 +98,7 @@ __global__ void __launch_bounds__(256) k_conv3x3_f32(ConvP p)
 #pragma unroll
         for (int it = 0; it < XN; ++it) {
             const int idx = t + it * 256;
-            if (idx < CV_CC * CV_XH * CV_XW) (&Xs[0][0][0])[idx] = xr[it];
+            if (idx < CV_CC * XH * CV_XW) (&Xs[0][0][0])[idx] = xr[it];
         }
 #pragma unroll
         for (int it = 0; it < WN; ++it) {
@@ -104,21 +111,22 @@ __global__ void __launch_bounds__(256) k_conv3x3_f32(ConvP p)
 #pragma unroll
         for (int cp = 0; cp < CV_CC / 2; ++cp) {
             const int ch = cp + (CV_CC / 2) * hh;
-            float xv[4][3];
+            float xv[RW + 2][3];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < RW + 2; ++r)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) xv[r][j] = Xs[ch][r0 + r][l31 + j];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    const float a0 = Ws[l31][ch * 9 + i * 3 + j];
-                    const float a1 = Ws[32 + l31][ch * 9 + i * 3 + j];
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, xv[i][j], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, xv[i + 1][j], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, xv[i][j], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, xv[i + 1][j], acc[1][1], 0, 0, 0);
+#pragma unroll
+                    for (int ob = 0; ob < OBW; ++ob) {
+                        const float a = Ws[(ob0 + ob) * 32 + l31][ch * 9 + i * 3 + j];
+#pragma unroll
+                        for (int rr = 0; rr < RW; ++rr)
+                            acc[ob][rr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xv[i + rr][j], acc[ob][rr], 0, 0, 0);
+                    }
                 }
         }
         __syncthreads();
@@ -128,14 +136,14 @@ __global__ void __launch_bounds__(256) k_conv3x3_f32(ConvP p)
     const int gw = w0 + l31;
     if (gw >= W) return;
 #pragma unroll
-    for (int ob = 0; ob < 2; ++ob)
+    for (int ob = 0; ob < OBW; ++ob)
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
+        for (int rr = 0; rr < RW; ++rr) {
             const int gh = h0 + r0 + rr;
             if (gh >= H) continue;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int o = o0 + ob * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                const int o = o0 + (ob0 + ob) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
                 if (o >= p.O) continue;
                 float v = acc[ob][rr][reg];
                 if (p.bias) v += p.bias[o];
@@ -154,9 +162,15 @@ __global__ void __launch_bounds__(256) k_conv3x3_f32(ConvP p)
 }
 
 // Small images leave most CUs idle: split the input channels over work-groups (plain epilogue only).
+static bool conv_small(int B, int O, int H, int W)
+{
+    return (long)orn_cdiv(W, CV_TW) * orn_cdiv(H, CV_TH) * orn_cdiv(O, CV_BO) * B < 256;
+}
+
 int orn_conv3x3_f32_nsplit(int B, int C, int O, int H, int W)
 {
-    const long wgs = (long)orn_cdiv(W, CV_TW) * orn_cdiv(H, CV_TH) * orn_cdiv(O, CV_BO) * B;
+    const int th = conv_small(B, O, H, W) ? 2 : CV_TH;
+    const long wgs = (long)orn_cdiv(W, CV_TW) * orn_cdiv(H, th) * orn_cdiv(O, CV_BO) * B;
     int ns = (int)(512 / (wgs > 0 ? wgs : 1));
     const int maxs = orn_cdiv(C, 2 * CV_CC);
     if (ns > maxs) ns = maxs;
@@ -169,8 +183,9 @@ int orn_launch_conv3x3_f32(const float *x, const float *w, const float *bias, in
     ConvP p;
     p.x = x; p.w = w; p.bias = bias; p.out = out; p.z = z;
     p.B = B; p.C = C; p.O = O; p.H = H; p.W = W; p.s = s;
+    const bool small = conv_small(B, O, H, W);
     p.tiles_w = orn_cdiv(W, CV_TW);
-    p.tiles_h = orn_cdiv(H, CV_TH);
+    p.tiles_h = orn_cdiv(H, small ? 2 : CV_TH);
     p.nsplit = 1; p.c_per_split = C;
     if (epi == EPI_PLAIN && split_ws && !bias) {
         const int ns = orn_conv3x3_f32_nsplit(B, C, O, H, W);
@@ -179,15 +194,21 @@ int orn_launch_conv3x3_f32(const float *x, const float *w, const float *bias, in
             p.nsplit = orn_cdiv(C, p.c_per_split);
             p.out = split_ws;
             dim3 grid(p.tiles_w * p.tiles_h, orn_cdiv(O, CV_BO), B * p.nsplit);
-            hipLaunchKernelGGL(k_conv3x3_f32<EPI_PLAIN>, grid, dim3(256), 0, st, p);
+            if (small) hipLaunchKernelGGL((k_conv3x3_f32<EPI_PLAIN, 1>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((k_conv3x3_f32<EPI_PLAIN, 0>), grid, dim3(256), 0, st, p);
             ORN_LAUNCH_CHECK("conv3x3_f32(split)");
             const size_t n = (size_t)B * O * H * W;
             return orn_launch_reduce_rows(split_ws, p.nsplit, n, n, out, st);
         }
     }
     dim3 grid(p.tiles_w * p.tiles_h, orn_cdiv(O, CV_BO), B);
-    if (epi == EPI_PS_SILU) hipLaunchKernelGGL(k_conv3x3_f32<EPI_PS_SILU>, grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(k_conv3x3_f32<EPI_PLAIN>, grid, dim3(256), 0, st, p);
+    if (epi == EPI_PS_SILU) {
+        if (small) hipLaunchKernelGGL((k_conv3x3_f32<EPI_PS_SILU, 1>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((k_conv3x3_f32<EPI_PS_SILU, 0>), grid, dim3(256), 0, st, p);
+    } else {
+        if (small) hipLaunchKernelGGL((k_conv3x3_f32<EPI_PLAIN, 1>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((k_conv3x3_f32<EPI_PLAIN, 0>), grid, dim3(256), 0, st, p);
+    }
     ORN_LAUNCH_CHECK("conv3x3_f32");
     return 0;
 }
