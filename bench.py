@@ -37,7 +37,7 @@ def layer_geo():
     return out
 
 
-def make_engine(seed, precision, branch_type='ERB'):
+def make_engine(seed, precision, branch_type='ERB', noise=0.1):
     from orn_amd import engine, model, ops
     from orn_amd.data import synthetic_video
     torch.manual_seed(1)                                    # main_train.py:162
@@ -47,7 +47,7 @@ def make_engine(seed, precision, branch_type='ERB'):
                           lower_width=CFG['lower_width'], sigmoid=False, deploy=False, branch_type=branch_type)
     eng = engine.TrainEngine(gen, loss_type=CFG['loss'], beta=CFG['beta'], precision=precision)
     n = CFG['frames']
-    frames = synthetic_video(n, 720, 1280, seed=seed, device=eng.device)
+    frames = synthetic_video(n, 720, 1280, seed=seed, device=eng.device, noise=noise)
     pos = torch.tensor([float(k) / n for k in range(n)], dtype=torch.float32)
     embeds = ops.pe_forward(pos.to(eng.device), 1.25, 40)
     eng.set_video(frames, embeds)

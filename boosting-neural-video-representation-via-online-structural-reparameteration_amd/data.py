@@ -5,9 +5,9 @@ import math
 import torch
 
 
-def synthetic_video(frames: int, h: int, w: int, seed: int = 1234, device='cuda') -> torch.Tensor:
+def synthetic_video(frames: int, h: int, w: int, seed: int = 1234, device='cuda', noise: float = 0.1) -> torch.Tensor:
     """[frames,3,h,w] fp32 in [0,1]: V[k] = clip(0.5 + sum_4 (0.25/4) sin(2pi(fx x + fy y + k/frames + ph))
-    + 0.1 U(-1,1)) with 4 random (fx, fy, ph) per channel (SURVEY 8d recipe).  Deterministic per seed."""
+    + noise*U(-1,1)) with 4 random (fx, fy, ph) per channel (SURVEY 8d recipe).  Deterministic per seed."""
     g = torch.Generator(device='cpu').manual_seed(seed)
     ys = torch.linspace(0, 1, h, device=device).view(1, 1, h, 1)
     xs = torch.linspace(0, 1, w, device=device).view(1, 1, 1, w)
@@ -19,8 +19,9 @@ def synthetic_video(frames: int, h: int, w: int, seed: int = 1234, device='cuda'
         ph = torch.rand(3, generator=g).view(1, 3, 1, 1).to(device)
         v += (0.25 / 4) * torch.sin(2 * math.pi * (fx * xs + fy * ys + ks + ph))
     gd = torch.Generator(device=device).manual_seed(seed)
+    noise_amp = noise
     noise = torch.rand((frames, 3, h, w), generator=gd, device=device)
-    v += 0.1 * (noise * 2 - 1)
+    v += noise_amp * (noise * 2 - 1)
     return v.clamp_(0, 1).contiguous()
 
 
