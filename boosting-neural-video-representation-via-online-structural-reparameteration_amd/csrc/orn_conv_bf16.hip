@@ -23,6 +23,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
+static int g_conv_dbg = 0;   // timing experiments only (tools/probes), see orn_debug_set
 #define MFMA_H16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
 #define CB_TH 8
@@ -339,7 +340,6 @@ static int launch_conv_cfg(const ConvBP &p, int n_tiles_total, hipStream_t st)
     return 0;
 }
 
-static int g_conv_dbg = 0;
 extern "C" void orn_debug_set(int flags) { g_conv_dbg = flags; }   // timing experiments only (tools/probes)
 
 // fwd: N tile 128 (waves 4x2, wave tile 64 px x 64 ch); dgrad: N = 96 in one tile (waves 8x1, 32 px x 96 ch)
@@ -393,6 +393,7 @@ struct WgradBP {
     float *bias_slabs;  // [S][O]  (column sums of dy, from the ti == 1 work-groups)
     int H, W, O;
     int tiles_w, n_ktiles, S, n_otiles;
+    int dbg;            // timing-only ablation flags (tools/probes)
 };
 
 __device__ __forceinline__ h16x8 tr_frag(const unsigned char *base0, const unsigned char *base1)
@@ -457,7 +458,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p)
             const int r = px / WB_TW, c = px - r * WB_TW;
             const int gh = h0 + r, gw = w0 + c;
             dv[it] = u32x4{0u, 0u, 0u, 0u};
-            if (gh < H && gw < W) dv[it] = *reinterpret_cast<const u32x4 *>(p.dypad + ((size_t)(gh + 1) * (W + 2) + (gw + 1)) * O + o0 + ch * 8);
+            if (gh < H && gw < W && !(p.dbg & 1)) dv[it] = *reinterpret_cast<const u32x4 *>(p.dypad + ((size_t)(gh + 1) * (W + 2) + (gw + 1)) * O + o0 + ch * 8);
         }
 #pragma unroll
         for (int it = 0; it < XN; ++it) {
@@ -466,7 +467,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p)
             const int r = px / WB_XW, c = px - r * WB_XW;
             const int gh = h0 + r + ti, gw = w0 + c;          // padded coords of x
             xv[it] = u32x4{0u, 0u, 0u, 0u};
-            if (idx < WB_TH * WB_XW * 12 && gh < H + 2 && gw < W + 2)
+            if (idx < WB_TH * WB_XW * 12 && gh < H + 2 && gw < W + 2 && !(p.dbg & 1))
                 xv[it] = *reinterpret_cast<const u32x4 *>(p.xpad + ((size_t)gh * (W + 2) + gw) * 96 + ch * 8);
         }
 #pragma unroll
@@ -557,6 +558,7 @@ int orn_launch_wgrad_bf16(const h16 *xpad, const h16 *dypad, int H, int W, int C
 {
     ORN_REQUIRE(C == 96 && O % WB_BO == 0 && O % (s * s) == 0, "wgrad_bf16: unsupported C=%d O=%d", C, O);
     WgradBP p;
+    p.dbg = g_conv_dbg;
     p.xpad = xpad; p.dypad = dypad; p.slabs = slabs; p.H = H; p.W = W; p.O = O;
     p.tiles_w = orn_cdiv(W, WB_TW);
     p.n_ktiles = p.tiles_w * orn_cdiv(H, WB_TH);
@@ -994,4 +996,17 @@ extern "C" int orn_conv_nhwc_bf16_fwd(const void *xpad, const void *wb, const fl
     ORN_REQUIRE(xpad && wb && z, "conv_nhwc_bf16_fwd: null pointer");
     return orn_launch_conv_bf16_fwd((const h16 *)xpad, (const h16 *)wb, bias_p, H, W, C, O, s, (h16 *)z, (h16 *)apad,
                                     (hipStream_t)stream);
+}
+
+extern "C" int orn_wgrad_nhwc_bf16(const void *xpad, const void *dypad, int H, int W, int C, int O, int s, float *slabs,
+                                   float *dwf, float *dbf, void *stream)
+{
+    return orn_launch_wgrad_bf16((const h16 *)xpad, (const h16 *)dypad, H, W, C, O, s, 1.0f, slabs, dwf, dbf, (hipStream_t)stream);
+}
+extern "C" size_t orn_wgrad_nhwc_bf16_ws_bytes(int H, int W, int O) { return orn_wgrad_bf16_ws_floats(H, W, O) * 4; }
+extern "C" int orn_dgrad_nhwc_bf16(const void *dypad, const void *wd, int H, int W, int O, int C, const void *zprev,
+                                   void *dyprev, int sp, void *stream)
+{
+    return orn_launch_conv_bf16_dgrad((const h16 *)dypad, (const h16 *)wd, H, W, O, C, (const h16 *)zprev, (h16 *)dyprev, sp,
+                                      nullptr, (hipStream_t)stream);
 }

@@ -98,6 +98,16 @@ int orn_conv3x3_ps_silu_bwd_bf16(const float *x, const float *wf, const float *z
 int orn_conv_nhwc_bf16_fwd(const void *xpad, const void *wb, const float *bias_p, int H, int W, int C, int O,
                            int s, void *z, void *apad, void *stream);
 
+/* Same for the two backward kernels (dgrad fused with SiLU' + un-shuffle into the previous layer's dypad;
+ * wgrad + dbias into PyTorch-layout dwf [O][96][3][3], dbf [O]) and a timing-only ablation switch for
+ * tools/probes (flags make results wrong; 0 restores normal operation). */
+int orn_dgrad_nhwc_bf16(const void *dypad, const void *wd, int H, int W, int O, int C, const void *zprev,
+                        void *dyprev, int sp, void *stream);
+size_t orn_wgrad_nhwc_bf16_ws_bytes(int H, int W, int O);
+int orn_wgrad_nhwc_bf16(const void *xpad, const void *dypad, int H, int W, int C, int O, int s, float *slabs,
+                        float *dwf, float *dbf, void *stream);
+void orn_debug_set(int flags);
+
 /* ---- A5  head: 1x1 conv -> (tanh+1)/2 or sigmoid                      model.py:621-622 --------
  * a [B,C,H,W]; w [3,C,1,1]; b [3]; out [B,3,H,W]. */
 int orn_head_fwd(const float *a, const float *w, const float *b, int B, int C, int H, int W, int sigmoid,
