@@ -87,10 +87,21 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
     constexpr int NT = WAVES_M * WAVES_N * 64;
     constexpr int BN = WAVES_N * NB * 32;
     static_assert(WAVES_M * MB == CB_TH, "M tile must be 8 rows of 32 pixels");
+    // LDS images: UNPADDED 192-byte rows (12 x 16-byte chunks) filled by LDS-DMA (global_load_lds_dwordx4: 1 KiB per
+    // wave-instruction, lane-linear destination, no VGPRs, no ds_write).  Conflict-free ds_read_b128 comes from a
+    // rotation swizzle -- logical chunk c of row R sits at position (c + ((R >> 2) & 3)) % 12 -- applied on the DMA's
+    // per-lane SOURCE address and on the fragment reads (both sides or neither: guide rule 21).
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NWAVES = WAVES_M * WAVES_N;
+    constexpr int ROWB = 192;
+    constexpr int PATCH_LDS = 65536;                   // 340 pixels x 192 B = 65,280 -> 64 wave-instructions
+    constexpr int BS_BYTES = BN * ROWB;
+    constexpr int B_INSTR = BS_BYTES / 1024;           // wave-instructions per weight tile
+    constexpr int B_PER_WAVE = (B_INSTR + NWAVES - 1) / NWAVES;
+    constexpr int P_PER_WAVE = 64 / NWAVES;
+    static_assert(NWAVES == 8 && BS_BYTES % 1024 == 0, "tile geometry");
     unsigned char *patch = smem;
-    unsigned char *bs0 = smem + CB_PATCH_BYTES;
-    constexpr int BS_BYTES = BN * CB_ROWB;
+    unsigned char *bs0 = smem + PATCH_LDS;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
@@ -110,63 +121,60 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
     const int Q = Cin / CB_CK;
     const int n_tiles = Q * 9;                         // weight tiles per N tile
 
-    constexpr int B_CHUNKS = BN * 12;                  // 16-byte chunks per weight tile
-    constexpr int B_PER_THR = (B_CHUNKS + NT - 1) / NT;
-    u32x4 breg[B_PER_THR];
-    int b_goff[B_PER_THR], b_loff[B_PER_THR];          // loop-invariant per-thread global / LDS offsets
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);        // provably wave-uniform (LDS-DMA base -> M0)
+    // per-lane SOURCE offsets (elements) of this wave's DMA instructions; rot() un-swizzles position -> logical chunk
+    int b_goff[B_PER_WAVE], p_goff[P_PER_WAVE];
+    bool p_ok[P_PER_WAVE];
 #pragma unroll
-    for (int it = 0; it < B_PER_THR; ++it) {
-        const int idx = t + it * NT;
-        const int row = idx / 12, ch = idx - row * 12;
-        b_goff[it] = row * Cin + ch * 8;
-        b_loff[it] = row * CB_ROWB + ch * 16;
+    for (int k = 0; k < B_PER_WAVE; ++k) {
+        const int m = (uwave + NWAVES * k) % B_INSTR;              // surplus instructions re-load a tile piece (harmless)
+        const int L = m * 64 + lane, R = L / 12, pos = L - R * 12;
+        const int c = (pos - ((R >> 2) & 3) + 12) % 12;
+        b_goff[k] = R * Cin + c * 8;
     }
-
-    // weight-tile staging through registers (macros, not lambdas: the register array must stay in VGPRs)
-#define LOAD_B(nt_, q_, tap_)                                                                                   \
+#pragma unroll
+    for (int k = 0; k < P_PER_WAVE; ++k) {
+        const int m = uwave + NWAVES * k;
+        const int L = m * 64 + lane, pix = L / 12, pos = L - pix * 12;
+        const int c = (pos - ((pix >> 2) & 3) + 12) % 12;
+        const int pr = pix / CB_PW, pc = pix - pr * CB_PW;
+        const int gh = h0 + pr, gw_ = w0 + pc;
+        p_ok[k] = (pix < CB_PH * CB_PW) && gh < H + 2 && gw_ < W + 2;
+        // out-of-image pixels read the (0,0) border pixel, which is all zeros
+        p_goff[k] = p_ok[k] ? ((gh * (W + 2) + gw_) * Cin + c * 8) : c * 8;
+    }
+#define DMA16(gptr_, ldsoff_)                                                                                   \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr_),                   \
+                                     (__attribute__((address_space(3))) void *)(smem + (ldsoff_)), 16, 0, 0)
+#define DMA_B(buf_, nt_, q_, tap_)                                                                              \
     {                                                                                                           \
         const h16 *wbase = p.w + ((size_t)((tap_) * p.Nout + (nt_) * BN) * Cin + (q_) * CB_CK);                 \
-        _Pragma("unroll") for (int it = 0; it < B_PER_THR; ++it)                                                \
-            if (B_CHUNKS % NT == 0 || t + it * NT < B_CHUNKS)                                                   \
-                breg[it] = *reinterpret_cast<const u32x4 *>(wbase + b_goff[it]);                                \
+        _Pragma("unroll") for (int k = 0; k < B_PER_WAVE; ++k)                                                  \
+            DMA16(wbase + b_goff[k], PATCH_LDS + (buf_) * BS_BYTES + ((uwave + NWAVES * k) % B_INSTR) * 1024);  \
     }
-#define STORE_B(buf_)                                                                                           \
+#define DMA_PATCH(q_)                                                                                           \
     {                                                                                                           \
-        unsigned char *lbase = bs0 + (buf_) * BS_BYTES;                                                         \
-        _Pragma("unroll") for (int it = 0; it < B_PER_THR; ++it)                                                \
-            if (B_CHUNKS % NT == 0 || t + it * NT < B_CHUNKS)                                                   \
-                *reinterpret_cast<u32x4 *>(lbase + b_loff[it]) = breg[it];                                      \
+        _Pragma("unroll") for (int k = 0; k < P_PER_WAVE; ++k)                                                  \
+            DMA16(p.xpad + p_goff[k] + (p_ok[k] ? (q_) * CB_CK : 0), (uwave + NWAVES * k) * 1024);              \
     }
-    // patch staging: all global loads in flight first, then the LDS writes (one latency, not eight)
-    constexpr int P_CHUNKS = CB_PH * CB_PW * 12;
-    constexpr int P_PER_THR = (P_CHUNKS + NT - 1) / NT;
-#define STAGE_PATCH(q_)                                                                                         \
+#define WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory")
+#define BARRIER() __builtin_amdgcn_s_barrier()
+    // fragment reads: 16 bytes at logical chunk (2*ks + hh) of a row -> rotated position
+#define READ_FRAGS(A_, B_, buf_, ks_)                                                                           \
     {                                                                                                           \
-        u32x4 pv[P_PER_THR];                                                                                    \
-        _Pragma("unroll") for (int it = 0; it < P_PER_THR; ++it) {                                              \
-            const int idx = t + it * NT;                                                                        \
-            const int pix = idx / 12, ch = idx - pix * 12;                                                      \
-            const int pr = pix / CB_PW, pc = pix - pr * CB_PW;                                                  \
-            const int gh = h0 + pr, gw_ = w0 + pc;                                                              \
-            pv[it] = u32x4{0u, 0u, 0u, 0u};                                                                     \
-            if (idx < P_CHUNKS && gh < H + 2 && gw_ < W + 2)                                                    \
-                pv[it] = *reinterpret_cast<const u32x4 *>(p.xpad + ((size_t)gh * (W + 2) + gw_) * Cin + (q_) * CB_CK + ch * 8); \
+        _Pragma("unroll") for (int i = 0; i < MB; ++i) {                                                        \
+            int o = a_pos[i] + (ks_) * 32;                                                                      \
+            o -= (o >= ROWB) ? ROWB : 0;                                                                        \
+            A_[i] = *reinterpret_cast<const h16x8 *>(patch + a_row[i] + o);                                     \
         }                                                                                                       \
-        _Pragma("unroll") for (int it = 0; it < P_PER_THR; ++it) {                                              \
-            const int idx = t + it * NT;                                                                        \
-            const int pix = idx / 12, ch = idx - pix * 12;                                                      \
-            if (idx < P_CHUNKS) *reinterpret_cast<u32x4 *>(patch + pix * CB_PIXB + ch * 16) = pv[it];           \
-        }                                                                                                       \
-    }
-#define READ_FRAGS(A_, B_, buf_, pa_, ks_)                                                                      \
-    {                                                                                                           \
-        _Pragma("unroll") for (int i = 0; i < MB; ++i)                                                          \
-            A_[i] = *reinterpret_cast<const h16x8 *>((pa_) + i * CB_PW * CB_PIXB + (ks_) * 32);                 \
+        int ob = b_pos + (ks_) * 32;                                                                            \
+        ob -= (ob >= ROWB) ? ROWB : 0;                                                                          \
         _Pragma("unroll") for (int j = 0; j < NB; ++j)                                                          \
-            B_[j] = *reinterpret_cast<const h16x8 *>(bs0 + (buf_) * BS_BYTES + boff + j * 32 * CB_ROWB + (ks_) * 32); \
+            B_[j] = *reinterpret_cast<const h16x8 *>(bs0 + (buf_) * BS_BYTES + b_row + j * 32 * ROWB + ob);     \
     }
+    const int b_row = (wn * NB * 32 + l31) * ROWB;
+    const int b_pos = 16 * (hh + ((l31 >> 2) & 3));
 
-    bool next_b_loaded = false;
     for (int nti = 0; nti < nt_cnt; ++nti) {
         const int nt = nt0 + nti;
         // acc[i][j]: D rows = 32 output channels (A operand = weights), D cols = 32 pixels of one row
@@ -179,68 +187,55 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        // prologue: weight tiles 0 and 1 (+ the patch when it is not already resident).  Three LDS weight
-        // buffers: tile t+2 is written while tile t computes, so tile t+1 is complete one barrier
-        // early and its first fragments can be read BEFORE the barrier that ends tile t -- the matrix
-        // pipe does not drain at the per-tap barrier.
-        const int boff = (wn * NB * 32 + l31) * CB_ROWB + hh * 16;
-        if (!next_b_loaded) { LOAD_B(nt, 0, 0) }
-        next_b_loaded = false;
-        if (nti == 0 || Q > 1) {
-            __syncthreads();
-            if (!(p.dbg & 2)) STAGE_PATCH(0)
-        }
-        STORE_B(0)
-        if (n_tiles > 1) {
-            LOAD_B(nt, 0, 1)
-            STORE_B(1)
-        }
-        __syncthreads();
-        if (n_tiles > 2) { LOAD_B(nt, 0, 2) }
+        // prologue: every wave is done with the previous N tile's buffers -> DMA the patch (first N tile or
+        // multi-chunk input) and weight tiles 0, 1; tile 2 stays in flight behind the first barrier.
+        BARRIER();
+        if ((nti == 0 || Q > 1) && !(p.dbg & 2)) DMA_PATCH(0)
+        DMA_B(0, nt, 0, 0)
+        if (n_tiles > 1) DMA_B(1, nt, 0, 1)
+        WAIT_VM(0);
+        BARRIER();
+        if (n_tiles > 2) DMA_B(2, nt, 0, 2)
         h16x8 fa[2][MB], fb[2][NB];
-        {
-            const unsigned char *pa0 = patch + ((wm * MB + 0) * CB_PW + (l31 + 0)) * CB_PIXB + hh * 16;
-            READ_FRAGS(fa[0], fb[0], 0, pa0, 0)
-        }
         int buf = 0;
         for (int tt = 0; tt < n_tiles; ++tt) {
             const int q = tt / 9, tap = tt - q * 9;
             const int ti = tap / 3, tj = tap - ti * 3;
             const bool has_next = (tt + 1 < n_tiles);
-            const int qn = (tt + 1) / 9, tapn = (tt + 1) - qn * 9;
-            const int tin = tapn / 3, tjn = tapn - tin * 3;
+            const int qn = (tt + 1) / 9;
             const bool same_chunk = has_next && (qn == q);
-            const int bufn = (buf == 2) ? 0 : buf + 1;
-            const unsigned char *pa = patch + ((wm * MB + ti) * CB_PW + (l31 + tj)) * CB_PIXB + hh * 16;
-            const unsigned char *pan = patch + ((wm * MB + tin) * CB_PW + (l31 + tjn)) * CB_PIXB + hh * 16;
+            int a_row[MB], a_pos[MB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const int pix = (wm * MB + i + ti) * CB_PW + l31 + tj;
+                a_row[i] = pix * ROWB;
+                a_pos[i] = 16 * (hh + ((pix >> 2) & 3));
+            }
+            READ_FRAGS(fa[0], fb[0], buf, 0)
 #pragma unroll
             for (int ks = 0; ks < CB_CK / 16; ++ks) {
-                if (!(p.dbg & 16)) {
-                    if (ks + 1 < CB_CK / 16) READ_FRAGS(fa[(ks + 1) & 1], fb[(ks + 1) & 1], buf, pa, ks + 1)
-                    else if (same_chunk) READ_FRAGS(fa[0], fb[0], bufn, pan, 0)
-                }
+                if (ks + 1 < CB_CK / 16 && !(p.dbg & 16)) READ_FRAGS(fa[(ks + 1) & 1], fb[(ks + 1) & 1], buf, ks + 1)
 #pragma unroll
                 for (int i = 0; i < MB; ++i)
 #pragma unroll
                     for (int j = 0; j < NB; ++j) acc[i][j] = MFMA_H16(fb[ks & 1][j], fa[ks & 1][i], acc[i][j]);
             }
-            if (tt + 2 < n_tiles && !(p.dbg & 1)) { STORE_B((buf + 2) % 3) }
-            if (has_next && !same_chunk) {            // next chunk needs a new patch: everyone must be done reading
-                __syncthreads();
-                if (!(p.dbg & 2)) STAGE_PATCH(qn)
+            if (has_next) {
+                // tile tt+1 was issued two tiles ago: let only tile tt+2's DMA stay in flight, then rendezvous
+                if (tt + 2 < n_tiles) { if (B_PER_WAVE == 3) WAIT_VM(3); else WAIT_VM(2); }
+                else WAIT_VM(0);
+                if (!(p.dbg & 8)) BARRIER();
+                if (!same_chunk) {                  // everyone is done with the old chunk's patch
+                    if (!(p.dbg & 2)) DMA_PATCH(qn)
+                    WAIT_VM(0);
+                    BARRIER();
+                }
+                if (tt + 3 < n_tiles && !(p.dbg & 1)) {
+                    const int q3 = (tt + 3) / 9, tap3 = (tt + 3) - q3 * 9;
+                    DMA_B(buf, nt, q3, tap3)        // buffer of tile tt: free now
+                }
             }
-            if (!(p.dbg & 8)) __syncthreads();
-            if (tt + 3 < n_tiles && !(p.dbg & 1)) {
-                const int q3 = (tt + 3) / 9, tap3 = (tt + 3) - q3 * 9;
-                LOAD_B(nt, q3, tap3)
-            }
-            if (has_next && !same_chunk) READ_FRAGS(fa[0], fb[0], bufn, pan, 0)
-            buf = bufn;
-        }
-        // next N tile's first weight tile goes in flight before the epilogue's stores
-        if (nti + 1 < nt_cnt) {
-            LOAD_B(nt + 1, 0, 0)
-            next_b_loaded = true;
+            buf = (buf == 2) ? 0 : buf + 1;
         }
 
         // ---- epilogue --------------------------------------------------------------------------
@@ -308,9 +303,11 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
     }
 }
 
-#undef LOAD_B
-#undef STORE_B
-#undef STAGE_PATCH
+#undef DMA16
+#undef DMA_B
+#undef DMA_PATCH
+#undef WAIT_VM
+#undef BARRIER
 #undef READ_FRAGS
 
 template <int WAVES_M, int WAVES_N, int MB, int NB, int EPI>
@@ -318,7 +315,7 @@ static int launch_conv_cfg(const ConvBP &p, int n_tiles_total, hipStream_t st)
 {
     constexpr int BN = WAVES_N * NB * 32;
     constexpr int NT = WAVES_M * WAVES_N * 64;
-    const size_t smem = CB_PATCH_BYTES + 3 * (size_t)BN * CB_ROWB;
+    const size_t smem = 65536 + 3 * (size_t)BN * 192;
     auto kern = k_conv_nhwc_bf16<WAVES_M, WAVES_N, MB, NB, EPI>;
     static bool attr_done = false;
     if (!attr_done) {
