@@ -373,15 +373,17 @@ int orn_launch_conv_bf16_dgrad(const h16 *dypad, const h16 *wd, int H, int W, in
 // ================================================================================================
 // wgrad: dW[tap][o'][c] = sum_p dy[p][o'] * x[p + off(tap)][c]
 // ================================================================================================
-#define WB_TH 4
+#define WB_TH 2                  // K tile = 2 rows x 32 pixels
 #define WB_TW 32
 #define WB_NPX (WB_TH * WB_TW)
 #define WB_BO 128
-#define WB_DYB 320               // LDS bytes per dy pixel row (256 data + 64 pad: conflict-free tr reads)
-#define WB_XB 192                // LDS bytes per x pixel (96 ch, unpadded: conflict-free tr reads)
+#define WB_DYB 256               // LDS bytes per dy pixel row: unpadded, 16-byte chunks XOR-swizzled by (pixel & 3) << 2
+#define WB_XB 192                // LDS bytes per x pixel (96 ch, unpadded: conflict-free tr reads as is)
 #define WB_XW (WB_TW + 2)
-#define WB_DY_BYTES (WB_NPX * WB_DYB)
-#define WB_X_BYTES (WB_TH * WB_XW * WB_XB)
+#define WB_DY_BYTES (WB_NPX * WB_DYB)                        /* 16 KiB = 16 DMA wave-instructions */
+#define WB_X_INSTR ((WB_TH * WB_XW * 12 + 63) / 64)          /* 13 DMA wave-instructions          */
+#define WB_X_BYTES (WB_X_INSTR * 1024)
+#define WB_BUF_BYTES (WB_DY_BYTES + WB_X_BYTES)
 
 struct WgradBP {
     const h16 *xpad;    // [H+2][W+2][96]
@@ -405,12 +407,13 @@ __device__ __forceinline__ h16x8 tr_frag(const unsigned char *base0, const unsig
     return __builtin_bit_cast(h16x8, v);
 }
 
+// Both LDS images are filled by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction) into a 2-deep ring:
+// tile t+1 streams in while tile t feeds the matrix core; one barrier per tile; two work-groups per CU.
 __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *dys = smem;
-    unsigned char *xs = smem + WB_DY_BYTES;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
     const int l31 = lane & 31, hh = lane >> 5;
     const int g = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
     // XCD-aware decode: the 9 work-groups that share one pixel range sit on one XCD (speed only)
@@ -437,48 +440,61 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p)
     for (int e = 0; e < 8; ++e) ones[e] = (h16)1.0f;
     const bool do_bias = (ti == 1);
 
-    // per-lane transposed-read offsets (pixel part is added per K slice)
-    const int a_off = (8 * (g >> 1) + lq) * WB_DYB + (wave * 32 + 16 * (g & 1) + 4 * lp) * 2;
+    // per-lane transposed-read offsets (pixel part is added per K slice).  dy: this lane's pixels all have
+    // (pixel & 3) == lq, so the XOR swizzle is a per-lane constant.
+    const int a_chunk = uwave * 4 + 2 * (g & 1) + (lp >> 1);
+    const int a_off = (8 * (g >> 1) + lq) * WB_DYB + ((a_chunk ^ (lq << 2)) * 16) + (lp & 1) * 8;
     const int b_off = (8 * (g >> 1) + lq) * WB_XB + (16 * (g & 1) + 4 * lp) * 2;
 
+    // DMA plan of this wave: 4 dy instructions (64 pixels x 16 chunks / 4 waves) + up to 4 x instructions
+    constexpr int DY_PW = (WB_DY_BYTES / 1024) / 4;          // 4
+    constexpr int X_PW = (WB_X_INSTR + 3) / 4;               // 4 (13 instructions over 4 waves)
+    int dy_px[DY_PW], dy_c[DY_PW], x_px[X_PW], x_c[X_PW];
+#pragma unroll
+    for (int k = 0; k < DY_PW; ++k) {
+        const int L = (uwave + 4 * k) * 64 + lane;           // linear 16-byte slot
+        dy_px[k] = L >> 4;
+        dy_c[k] = (L & 15) ^ ((dy_px[k] & 3) << 2);          // logical chunk stored at this slot
+    }
+#pragma unroll
+    for (int k = 0; k < X_PW; ++k) {
+        const int L = (uwave + 4 * k) * 64 + lane;
+        x_px[k] = L / 12;
+        x_c[k] = L - x_px[k] * 12;
+    }
+#define WDMA16(gptr_, ldsoff_)                                                                                  \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr_),                   \
+                                     (__attribute__((address_space(3))) void *)(smem + (ldsoff_)), 16, 0, 0)
+#define WDMA_TILE(kt_, buf_)                                                                                    \
+    {                                                                                                           \
+        const int th_ = (kt_) / p.tiles_w, tw_ = (kt_) - th_ * p.tiles_w;                                       \
+        const int h0_ = th_ * WB_TH, w0_ = tw_ * WB_TW;                                                         \
+        _Pragma("unroll") for (int k = 0; k < DY_PW; ++k) {                                                     \
+            const int gh = h0_ + dy_px[k] / WB_TW, gw = w0_ + (dy_px[k] & (WB_TW - 1));                         \
+            const bool ok = gh < H && gw < W && !(p.dbg & 1);                                                   \
+            const h16 *src = ok ? p.dypad + ((size_t)(gh + 1) * (W + 2) + (gw + 1)) * O + o0 + dy_c[k] * 8      \
+                                : p.dypad + dy_c[k] * 8; /* border pixel (0,0): zeros */                        \
+            WDMA16(src, (buf_) * WB_BUF_BYTES + (uwave + 4 * k) * 1024);                                        \
+        }                                                                                                       \
+        _Pragma("unroll") for (int k = 0; k < X_PW; ++k) {                                                      \
+            if (uwave + 4 * k < WB_X_INSTR) {                                                                   \
+                const int r = x_px[k] / WB_XW, c = x_px[k] - r * WB_XW;                                         \
+                const int gh = h0_ + r + ti, gw = w0_ + c;                                                      \
+                const bool ok = x_px[k] < WB_TH * WB_XW && gh < H + 2 && gw < W + 2 && !(p.dbg & 1);            \
+                const h16 *src = ok ? p.xpad + ((size_t)gh * (W + 2) + gw) * 96 + x_c[k] * 8 : p.xpad + x_c[k] * 8; \
+                WDMA16(src, (buf_) * WB_BUF_BYTES + WB_DY_BYTES + (uwave + 4 * k) * 1024);                      \
+            }                                                                                                   \
+        }                                                                                                       \
+    }
+
+    int buf = 0;
+    if (sidx < p.n_ktiles) WDMA_TILE(sidx, 0)
     for (int kt = sidx; kt < p.n_ktiles; kt += p.S) {
-        const int th = kt / p.tiles_w, tw = kt - th * p.tiles_w;
-        const int h0 = th * WB_TH, w0 = tw * WB_TW;
-        __syncthreads();
-        // all global loads of the tile in flight before the first LDS write (one exposed latency per tile)
-        constexpr int DYN = (WB_NPX * 16) / 256, XN = (WB_TH * WB_XW * 12 + 255) / 256;
-        u32x4 dv[DYN], xv[XN];
-#pragma unroll
-        for (int it = 0; it < DYN; ++it) {
-            const int idx = t + it * 256;
-            const int px = idx >> 4, ch = idx & 15;
-            const int r = px / WB_TW, c = px - r * WB_TW;
-            const int gh = h0 + r, gw = w0 + c;
-            dv[it] = u32x4{0u, 0u, 0u, 0u};
-            if (gh < H && gw < W && !(p.dbg & 1)) dv[it] = *reinterpret_cast<const u32x4 *>(p.dypad + ((size_t)(gh + 1) * (W + 2) + (gw + 1)) * O + o0 + ch * 8);
-        }
-#pragma unroll
-        for (int it = 0; it < XN; ++it) {
-            const int idx = t + it * 256;
-            const int px = idx / 12, ch = idx - px * 12;
-            const int r = px / WB_XW, c = px - r * WB_XW;
-            const int gh = h0 + r + ti, gw = w0 + c;          // padded coords of x
-            xv[it] = u32x4{0u, 0u, 0u, 0u};
-            if (idx < WB_TH * WB_XW * 12 && gh < H + 2 && gw < W + 2 && !(p.dbg & 1))
-                xv[it] = *reinterpret_cast<const u32x4 *>(p.xpad + ((size_t)gh * (W + 2) + gw) * 96 + ch * 8);
-        }
-#pragma unroll
-        for (int it = 0; it < DYN; ++it) {
-            const int idx = t + it * 256;
-            *reinterpret_cast<u32x4 *>(dys + (idx >> 4) * WB_DYB + (idx & 15) * 16) = dv[it];
-        }
-#pragma unroll
-        for (int it = 0; it < XN; ++it) {
-            const int idx = t + it * 256;
-            const int px = idx / 12, ch = idx - px * 12;
-            if (idx < WB_TH * WB_XW * 12) *reinterpret_cast<u32x4 *>(xs + px * WB_XB + ch * 16) = xv[it];
-        }
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt have landed
+        __builtin_amdgcn_s_barrier();                         // ... everyone's have; everyone is done with tile kt - S
+        if (kt + p.S < p.n_ktiles) WDMA_TILE(kt + p.S, buf ^ 1)
+        const unsigned char *dys = smem + buf * WB_BUF_BYTES;
+        const unsigned char *xs = dys + WB_DY_BYTES;
 #pragma unroll
         for (int r = 0; r < WB_TH; ++r)
 #pragma unroll
@@ -496,7 +512,10 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p)
                     }
                 }
             }
+        buf ^= 1;
     }
+#undef WDMA16
+#undef WDMA_TILE
     if (do_bias && l31 == 0) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
@@ -527,8 +546,15 @@ __global__ void k_wgrad_bf16_reduce(const float *__restrict__ slabs, const float
         dbf[nn * s2 + ij] = b * gscale;
     }
     if (idx >= n) return;
-    float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc += slabs[(size_t)s * n + idx];
+    // 8 independent partial sums keep 8 loads in flight (fixed order -> still deterministic)
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a8[k] += slabs[(size_t)(s + k) * n + idx];
+    }
+    for (; s < S; ++s) a8[0] += slabs[(size_t)s * n + idx];
+    const float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
     const int c = (int)(idx % 96);
     const size_t r = idx / 96;
     const int op = (int)(r % O), tap = (int)(r / O);
@@ -563,7 +589,7 @@ int orn_launch_wgrad_bf16(const h16 *xpad, const h16 *dypad, int H, int W, int C
     p.bias_slabs = slabs + (size_t)p.S * 9 * O * 96;
     p.n_otiles = O / WB_BO;
     static bool attr_done = false;
-    const size_t smem = WB_DY_BYTES + WB_X_BYTES;
+    const size_t smem = 2 * WB_BUF_BYTES;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void *)k_wgrad_nhwc_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) { orn_set_error("wgrad_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
