@@ -68,6 +68,7 @@ struct ConvBP {
     int H, W, Cin, Nout;
     int tiles_w, tiles_h, n_tiles_per_wg;
     int n_full;          // work-groups [0, n_full) own whole pixel tiles; the rest own one N tile each
+    int qsplit;          // EPI_B_DGRAD_F32 on small images: blockIdx.y = input chunk, one fp32 partial slab per chunk
     // EPI_B_FWD
     h16 *z;              // [H*s][W*s][Cn]
     h16 *apad;           // [H*s+2][W*s+2][Cn] or null
@@ -118,7 +119,9 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
     const int tw = tile % p.tiles_w, th = tile / p.tiles_w;
     const int h0 = th * CB_TH, w0 = tw * CB_TW;
     const int H = p.H, W = p.W, Cin = p.Cin;
-    const int Q = Cin / CB_CK;
+    const int q_base = (EPI == EPI_B_DGRAD_F32 && p.qsplit) ? (int)blockIdx.y : 0;   // chunk split: this WG's chunk
+    const int Q = (EPI == EPI_B_DGRAD_F32 && p.qsplit) ? 1 : Cin / CB_CK;
+    if (EPI == EPI_B_DGRAD_F32 && p.qsplit) nt0 = 0;
     const int n_tiles = Q * 9;                         // weight tiles per N tile
 
     const int uwave = __builtin_amdgcn_readfirstlane(wave);        // provably wave-uniform (LDS-DMA base -> M0)
@@ -148,14 +151,14 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
                                      (__attribute__((address_space(3))) void *)(smem + (ldsoff_)), 16, 0, 0)
 #define DMA_B(buf_, nt_, q_, tap_)                                                                              \
     {                                                                                                           \
-        const h16 *wbase = p.w + ((size_t)((tap_) * p.Nout + (nt_) * BN) * Cin + (q_) * CB_CK);                 \
+        const h16 *wbase = p.w + ((size_t)((tap_) * p.Nout + (nt_) * BN) * Cin + ((q_) + q_base) * CB_CK);      \
         _Pragma("unroll") for (int k = 0; k < B_PER_WAVE; ++k)                                                  \
             DMA16(wbase + b_goff[k], PATCH_LDS + (buf_) * BS_BYTES + ((uwave + NWAVES * k) % B_INSTR) * 1024);  \
     }
 #define DMA_PATCH(q_)                                                                                           \
     {                                                                                                           \
         _Pragma("unroll") for (int k = 0; k < P_PER_WAVE; ++k)                                                  \
-            DMA16(p.xpad + p_goff[k] + (p_ok[k] ? (q_) * CB_CK : 0), (uwave + NWAVES * k) * 1024);              \
+            DMA16(p.xpad + p_goff[k] + (p_ok[k] ? ((q_) + q_base) * CB_CK : 0), (uwave + NWAVES * k) * 1024);   \
     }
 #define WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory")
 #define BARRIER() __builtin_amdgcn_s_barrier()
@@ -175,6 +178,23 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
     const int b_row = (wn * NB * 32 + l31) * ROWB;
     const int b_pos = 16 * (hh + ((l31 >> 2) & 3));
 
+    // EPI_B_FWD: the packed outputs of an N tile are stored AFTER the next N tile's prologue rendezvous, so the
+    // store drain overlaps the next main loop instead of stalling the prologue's vmcnt(0)
+    constexpr int NDEF = (EPI == EPI_B_FWD) ? MB * NB * 2 : 1;
+    u32x4 dz[NDEF], da[NDEF];
+    int dzo[NDEF], dao[NDEF];
+    bool dok[NDEF];
+    bool pending = false;
+#define FLUSH_DEFERRED()                                                                                        \
+    {                                                                                                           \
+        _Pragma("unroll") for (int e_ = 0; e_ < NDEF; ++e_) {                                                   \
+            if (dok[e_]) {                                                                                      \
+                *reinterpret_cast<u32x4 *>(p.z + dzo[e_]) = dz[e_];                                             \
+                if (p.apad) *reinterpret_cast<u32x4 *>(p.apad + dao[e_]) = da[e_];                              \
+            }                                                                                                   \
+        }                                                                                                       \
+        pending = false;                                                                                        \
+    }
     for (int nti = 0; nti < nt_cnt; ++nti) {
         const int nt = nt0 + nti;
         // acc[i][j]: D rows = 32 output channels (A operand = weights), D cols = 32 pixels of one row
@@ -196,6 +216,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
         WAIT_VM(0);
         BARRIER();
         if (n_tiles > 2) DMA_B(2, nt, 0, 2)
+        if (EPI == EPI_B_FWD && pending) FLUSH_DEFERRED()
         h16x8 fa[2][MB], fb[2][NB];
         int buf = 0;
         for (int tt = 0; tt < n_tiles; ++tt) {
@@ -266,12 +287,17 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
                         swap_halves(za0, zb0); swap_halves(za1, zb1);
                         const int ij = c8 / p.Cn, n = c8 - ij * p.Cn, si = ij / p.s, sj = ij - si * p.s;
                         const int Ws = W * p.s, oh = gh * p.s + si, ow = gw * p.s + sj;
-                        if (ok) *reinterpret_cast<u32x4 *>(p.z + ((size_t)oh * Ws + ow) * p.Cn + n) = u32x4{za0, za1, zb0, zb1};
+                        constexpr int DI_ = 0;
+                        const int di = (EPI == EPI_B_FWD) ? ((i * NB + j) * 2 + k / 2) : DI_;
+                        dz[di] = u32x4{za0, za1, zb0, zb1};
+                        dzo[di] = (int)(((size_t)oh * Ws + ow) * p.Cn + n);
+                        dok[di] = ok;
                         if (p.apad) {
                             unsigned aa0 = pack_h16x2(orn_silu(va[0]), orn_silu(va[1])), aa1 = pack_h16x2(orn_silu(va[2]), orn_silu(va[3]));
                             unsigned ab0 = pack_h16x2(orn_silu(vb[0]), orn_silu(vb[1])), ab1 = pack_h16x2(orn_silu(vb[2]), orn_silu(vb[3]));
                             swap_halves(aa0, ab0); swap_halves(aa1, ab1);
-                            if (ok) *reinterpret_cast<u32x4 *>(p.apad + ((size_t)(oh + 1) * (Ws + 2) + (ow + 1)) * p.Cn + n) = u32x4{aa0, aa1, ab0, ab1};
+                            da[di] = u32x4{aa0, aa1, ab0, ab1};
+                            dao[di] = (int)(((size_t)(oh + 1) * (Ws + 2) + (ow + 1)) * p.Cn + n);
                         }
                     } else {
                         float v[8];
@@ -292,7 +318,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
                                                            sub * p.Nout + c8) = o8;
                             }
                         } else if (ok) {
-                            float *dst = p.dx_f32 + ((size_t)gh * W + gw) * p.Nout + c8;
+                            float *dst = p.dx_f32 + (size_t)q_base * H * W * p.Nout + ((size_t)gh * W + gw) * p.Nout + c8;
                             *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                             *reinterpret_cast<float4 *>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
                         }
@@ -300,9 +326,12 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
                 }
             }
         }
+        if (EPI == EPI_B_FWD) pending = true;
     }
+    if (EPI == EPI_B_FWD && pending) FLUSH_DEFERRED()
 }
 
+#undef FLUSH_DEFERRED
 #undef DMA16
 #undef DMA_B
 #undef DMA_PATCH
@@ -326,6 +355,7 @@ static int launch_conv_cfg(const ConvBP &p, int n_tiles_total, hipStream_t st)
     const int ptiles = p.tiles_w * p.tiles_h;
     ConvBP q = p;
     dim3 grid(ptiles, n_tiles_total / p.n_tiles_per_wg);
+    if (p.qsplit) grid.y = p.Cin / CB_CK;
     q.n_full = ptiles;
     if (p.n_tiles_per_wg > 1 && p.n_tiles_per_wg == n_tiles_total) {
         // 256 CUs, one work-group each: whole rounds keep full tiles, the last partial round is cut up
@@ -355,6 +385,12 @@ int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p
     return launch_conv_cfg<4, 2, 2, 2, EPI_B_FWD>(p, nt_total, st);
 }
 
+// dx_f32 must hold orn_dgrad_f32_slabs(H, W, O) partial slabs of H*W*C floats; the NCHW convert sums them.
+int orn_dgrad_f32_slabs(int H, int W, int O)
+{
+    return (orn_cdiv(W, CB_TW) * orn_cdiv(H, CB_TH) < 128 && O / CB_CK > 1) ? O / CB_CK : 1;
+}
+
 int orn_launch_conv_bf16_dgrad(const h16 *dypad, const h16 *wd, int H, int W, int O, int C, const h16 *zprev,
                                h16 *dyprev, int sp, float *dx_f32, hipStream_t st)
 {
@@ -365,7 +401,10 @@ int orn_launch_conv_bf16_dgrad(const h16 *dypad, const h16 *wd, int H, int W, in
     p.tiles_w = orn_cdiv(W, CB_TW); p.tiles_h = orn_cdiv(H, CB_TH);
     p.n_tiles_per_wg = 1;
     p.zprev = zprev; p.dyprev = dyprev; p.sp = sp; p.dx_f32 = dx_f32;
-    if (dx_f32) return launch_conv_cfg<8, 1, 1, 3, EPI_B_DGRAD_F32>(p, 1, st);
+    if (dx_f32) {
+        p.qsplit = (p.tiles_w * p.tiles_h < 128 && O / CB_CK > 1) ? 1 : 0;   // few pixel tiles: one work-group per input chunk
+        return launch_conv_cfg<8, 1, 1, 3, EPI_B_DGRAD_F32>(p, 1, st);
+    }
     ORN_REQUIRE(zprev && dyprev && sp >= 1 && H % sp == 0 && W % sp == 0, "conv_bf16_dgrad: bad epilogue arguments");
     return launch_conv_cfg<8, 1, 1, 3, EPI_B_DGRAD>(p, 1, st);
 }
@@ -648,14 +687,17 @@ __global__ void k_nchw_to_nhwc_pad_bf16(const float *__restrict__ src, int C, in
 }
 
 // fp32 NHWC [H][W][C] -> fp32 NCHW [C][H][W]
-__global__ void k_nhwc_to_nchw_f32(const float *__restrict__ src, int C, int H, int W, float *__restrict__ dst)
+__global__ void k_nhwc_to_nchw_f32(const float *__restrict__ src, int C, int H, int W, int nslab, float *__restrict__ dst)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)C * H * W) return;
+    const size_t n = (size_t)C * H * W;
+    if (idx >= n) return;
     const size_t HW = (size_t)H * W;
     const int c = (int)(idx / HW);
     const size_t pix = idx - (size_t)c * HW;
-    dst[idx] = src[pix * C + c];
+    float v = 0.f;
+    for (int s = 0; s < nslab; ++s) v += src[(size_t)s * n + pix * C + c];      // fixed order
+    dst[idx] = v;
 }
 
 int orn_launch_nchw_to_nhwc_pad_bf16(const float *src, int C, int H, int W, h16 *dst, hipStream_t st)
@@ -665,9 +707,9 @@ int orn_launch_nchw_to_nhwc_pad_bf16(const float *src, int C, int H, int W, h16 
     return 0;
 }
 
-int orn_launch_nhwc_to_nchw_f32(const float *src, int C, int H, int W, float *dst, hipStream_t st)
+int orn_launch_nhwc_to_nchw_f32(const float *src, int C, int H, int W, int nslab, float *dst, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_nhwc_to_nchw_f32, dim3(orn_cdiv((long)C * H * W, 256)), dim3(256), 0, st, src, C, H, W, dst);
+    hipLaunchKernelGGL(k_nhwc_to_nchw_f32, dim3(orn_cdiv((long)C * H * W, 256)), dim3(256), 0, st, src, C, H, W, nslab, dst);
     ORN_LAUNCH_CHECK("nhwc_to_nchw_f32");
     return 0;
 }
@@ -941,7 +983,7 @@ extern "C" size_t orn_conv3x3_ps_silu_bf16_ws_bytes(int C, int O, int H, int W, 
     b += alh((size_t)(H + 2) * (W + 2) * O) * 2;          // dypad
     b += orn_align(orn_wgrad_bf16_ws_floats(H, W, O) * 4);
     b += orn_align(orn_dbias_bf16_ws_floats(H, O) * 4);
-    b += orn_align((size_t)H * W * C * 4);                // dx fp32 NHWC
+    b += orn_align((size_t)H * W * C * 4 * 8);            // dx fp32 NHWC (up to 8 chunk slabs)
     return b;
 }
 
@@ -1007,7 +1049,7 @@ extern "C" int orn_conv3x3_ps_silu_bwd_bf16(const float *x, const float *wf, con
     ORN_TRY(orn_launch_wgrad_bf16(b.xpad, b.dypad, H, W, C, O, s, 1.0f, b.slabs, dwf, dbf, st));
     if (dx) {
         ORN_TRY(orn_launch_conv_bf16_dgrad(b.dypad, b.wd, H, W, O, C, nullptr, nullptr, 1, b.dxn, st));
-        ORN_TRY(orn_launch_nhwc_to_nchw_f32(b.dxn, C, H, W, dx, st));
+        ORN_TRY(orn_launch_nhwc_to_nchw_f32(b.dxn, C, H, W, orn_dgrad_f32_slabs(H, W, O), dx, st));
     }
     return 0;
 }

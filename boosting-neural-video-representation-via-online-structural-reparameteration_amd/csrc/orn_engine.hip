@@ -124,7 +124,7 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
             L[i].wb = (h16 *)take((wsz + 1) / 2);
             L[i].wd = (h16 *)take((wsz + 1) / 2);
             L[i].biasp = take(l.O);
-            if (i == ff) dxn = take((size_t)l.H * l.W * l.C);
+            if (i == ff) dxn = take((size_t)l.H * l.W * l.C * orn_dgrad_f32_slabs(l.H, l.W, l.O));
             s1 = al(orn_wgrad_bf16_ws_floats(l.H, l.W, l.O)) + al(orn_dbias_bf16_ws_floats(l.H, l.O));
         }
         if (d->erb) { const size_t s2 = orn_erb_merge_bwd_ws_bytes(l.C, l.O) / 4; if (s2 > s1) s1 = s2; }
@@ -342,7 +342,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
                                                    d.layer[i - 1].s, nullptr, st));
             } else {
                 ORN_TRY(orn_launch_conv_bf16_dgrad(b.dypad, b.wd, l.H, l.W, l.O, l.C, nullptr, nullptr, 1, e->dxn, st));
-                ORN_TRY(orn_launch_nhwc_to_nchw_f32(e->dxn, l.C, l.H, l.W, dx, st));
+                ORN_TRY(orn_launch_nhwc_to_nchw_f32(e->dxn, l.C, l.H, l.W, orn_dgrad_f32_slabs(l.H, l.W, l.O), dx, st));
             }
         } else
         ORN_TRY(orn_launch_conv_bwd_f32(x, b.wf, b.z, b.da, 1, l.C, l.O, l.H, l.W, l.s, dx, G + l.w3x3, G + l.b3x3, e->scratch, st));

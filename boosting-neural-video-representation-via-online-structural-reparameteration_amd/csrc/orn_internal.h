@@ -64,7 +64,8 @@ int orn_launch_wgrad_bf16(const h16 *xpad, const h16 *dypad, int H, int W, int C
 int orn_launch_prep_weights_bf16(const float *wf, const float *bf, int O, int C, int s, h16 *wb, h16 *wd, float *bias_p,
                                  hipStream_t st);
 int orn_launch_nchw_to_nhwc_pad_bf16(const float *src, int C, int H, int W, h16 *dst, hipStream_t st);
-int orn_launch_nhwc_to_nchw_f32(const float *src, int C, int H, int W, float *dst, hipStream_t st);
+int orn_launch_nhwc_to_nchw_f32(const float *src, int C, int H, int W, int nslab, float *dst, hipStream_t st);
+int orn_dgrad_f32_slabs(int H, int W, int O);
 size_t orn_dbias_bf16_ws_floats(int H, int O);
 int orn_launch_dbias_bf16(const h16 *dypad, int H, int W, int O, int s, float gscale, float *partial, float *dbf, hipStream_t st);
 int orn_launch_head_fwd_bf16(const h16 *z, const float *w, const float *b, int C, size_t HW, int sigmoid, float *out, hipStream_t st);
