@@ -666,6 +666,48 @@ __global__ void k_prep_weights_bf16(const float *__restrict__ wf, const float *_
     wd[((size_t)(8 - tap) * C + c) * O + op] = v;
 }
 
+struct OrnPrepLayer { const float *wf, *bf; int O, C, s; __bf16 *wb, *wd; float *biasp; };
+struct PrepAll {
+    int n;
+    struct { const float *wf, *bf; int O, C, Cn, s2; h16 *wb, *wd; float *biasp; } l[ORN_MAX_LAYERS];
+};
+
+__global__ void k_prep_weights_bf16_all(PrepAll a)
+{
+    const auto &l = a.l[blockIdx.y];
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (size_t)l.O) {
+        const int o = (int)idx;
+        l.biasp[(o % l.s2) * l.Cn + o / l.s2] = l.bf[o];
+    }
+    if (idx >= (size_t)l.O * l.C * 9) return;
+    const int tap = (int)(idx % 9);
+    const size_t oc = idx / 9;
+    const int c = (int)(oc % l.C), o = (int)(oc / l.C);
+    const int op = (o % l.s2) * l.Cn + o / l.s2;
+    const h16 v = (h16)l.wf[idx];
+    l.wb[((size_t)tap * l.O + op) * l.C + c] = v;
+    l.wd[((size_t)(8 - tap) * l.C + c) * l.O + op] = v;
+}
+
+int orn_launch_prep_weights_bf16_all(int n, const OrnPrepLayer *L, hipStream_t st)
+{
+    if (n == 0) return 0;
+    PrepAll a;
+    a.n = n;
+    size_t mx = 0;
+    for (int i = 0; i < n; ++i) {
+        a.l[i].wf = L[i].wf; a.l[i].bf = L[i].bf; a.l[i].O = L[i].O; a.l[i].C = L[i].C;
+        a.l[i].Cn = L[i].O / (L[i].s * L[i].s); a.l[i].s2 = L[i].s * L[i].s;
+        a.l[i].wb = L[i].wb; a.l[i].wd = L[i].wd; a.l[i].biasp = L[i].biasp;
+        const size_t w = (size_t)L[i].O * L[i].C * 9;
+        if (w > mx) mx = w;
+    }
+    hipLaunchKernelGGL(k_prep_weights_bf16_all, dim3(orn_cdiv((long)mx, 256), n), dim3(256), 0, st, a);
+    ORN_LAUNCH_CHECK("prep_weights_bf16_all");
+    return 0;
+}
+
 int orn_launch_prep_weights_bf16(const float *wf, const float *bf, int O, int C, int s, h16 *wb, h16 *wd, float *bias_p,
                                  hipStream_t st)
 {
@@ -675,41 +717,62 @@ int orn_launch_prep_weights_bf16(const float *wf, const float *bf, int O, int C,
     return 0;
 }
 
-// fp32 NCHW [C][H][W] -> bf16 padded NHWC [H+2][W+2][C] interior (border stays zero)
-__global__ void k_nchw_to_nhwc_pad_bf16(const float *__restrict__ src, int C, int H, int W, h16 *__restrict__ dst)
+// fp32 NCHW [C][H][W] -> bf16 padded NHWC [H+2][W+2][C] interior (border stays zero).
+// 64-pixel x C tile through LDS: coalesced along pixels on the read, along channels on the write.
+#define TR_PX 64
+#define TR_MAXC 128
+__global__ void __launch_bounds__(256) k_nchw_to_nhwc_pad_bf16(const float *__restrict__ src, int C, int H, int W, h16 *__restrict__ dst)
 {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)C * H * W) return;
-    const int c = (int)(idx % C);
-    const size_t pix = idx / C;
-    const int w = (int)(pix % W), h = (int)(pix / W);
-    dst[((size_t)(h + 1) * (W + 2) + (w + 1)) * C + c] = (h16)src[((size_t)c * H + h) * W + w];
+    __shared__ float tile[TR_MAXC][TR_PX + 1];
+    const size_t HW = (size_t)H * W;
+    const size_t p0 = (size_t)blockIdx.x * TR_PX;
+    for (int idx = threadIdx.x; idx < C * TR_PX; idx += 256) {
+        const int c = idx / TR_PX, px = idx - c * TR_PX;
+        tile[c][px] = (p0 + px < HW) ? src[(size_t)c * HW + p0 + px] : 0.f;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < C * TR_PX; idx += 256) {
+        const int px = idx / C, c = idx - px * C;
+        const size_t pix = p0 + px;
+        if (pix < HW) {
+            const int h = (int)(pix / W), w = (int)(pix - (size_t)h * W);
+            dst[((size_t)(h + 1) * (W + 2) + (w + 1)) * C + c] = (h16)tile[c][px];
+        }
+    }
 }
 
-// fp32 NHWC [H][W][C] -> fp32 NCHW [C][H][W]
-__global__ void k_nhwc_to_nchw_f32(const float *__restrict__ src, int C, int H, int W, int nslab, float *__restrict__ dst)
+// fp32 NHWC slabs [nslab][H][W][C] -> fp32 NCHW [C][H][W] (sum over slabs in fixed order), tiled through LDS
+__global__ void __launch_bounds__(256) k_nhwc_to_nchw_f32(const float *__restrict__ src, int C, int H, int W, int nslab, float *__restrict__ dst)
 {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t n = (size_t)C * H * W;
-    if (idx >= n) return;
-    const size_t HW = (size_t)H * W;
-    const int c = (int)(idx / HW);
-    const size_t pix = idx - (size_t)c * HW;
-    float v = 0.f;
-    for (int s = 0; s < nslab; ++s) v += src[(size_t)s * n + pix * C + c];      // fixed order
-    dst[idx] = v;
+    __shared__ float tile[TR_MAXC][TR_PX + 1];
+    const size_t HW = (size_t)H * W, n = HW * C;
+    const size_t p0 = (size_t)blockIdx.x * TR_PX;
+    for (int idx = threadIdx.x; idx < C * TR_PX; idx += 256) {
+        const int px = idx / C, c = idx - px * C;
+        float v = 0.f;
+        if (p0 + px < HW)
+            for (int s = 0; s < nslab; ++s) v += src[(size_t)s * n + (p0 + px) * C + c];
+        tile[c][px] = v;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < C * TR_PX; idx += 256) {
+        const int c = idx / TR_PX, px = idx - c * TR_PX;
+        if (p0 + px < HW) dst[(size_t)c * HW + p0 + px] = tile[c][px];
+    }
 }
 
 int orn_launch_nchw_to_nhwc_pad_bf16(const float *src, int C, int H, int W, h16 *dst, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_nchw_to_nhwc_pad_bf16, dim3(orn_cdiv((long)C * H * W, 256)), dim3(256), 0, st, src, C, H, W, dst);
+    ORN_REQUIRE(C <= TR_MAXC, "nchw_to_nhwc: C=%d > %d", C, TR_MAXC);
+    hipLaunchKernelGGL(k_nchw_to_nhwc_pad_bf16, dim3(orn_cdiv((long)H * W, TR_PX)), dim3(256), 0, st, src, C, H, W, dst);
     ORN_LAUNCH_CHECK("nchw_to_nhwc_pad_bf16");
     return 0;
 }
 
 int orn_launch_nhwc_to_nchw_f32(const float *src, int C, int H, int W, int nslab, float *dst, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_nhwc_to_nchw_f32, dim3(orn_cdiv((long)C * H * W, 256)), dim3(256), 0, st, src, C, H, W, nslab, dst);
+    ORN_REQUIRE(C <= TR_MAXC, "nhwc_to_nchw: C=%d > %d", C, TR_MAXC);
+    hipLaunchKernelGGL(k_nhwc_to_nchw_f32, dim3(orn_cdiv((long)H * W, TR_PX)), dim3(256), 0, st, src, C, H, W, nslab, dst);
     ORN_LAUNCH_CHECK("nhwc_to_nchw_f32");
     return 0;
 }

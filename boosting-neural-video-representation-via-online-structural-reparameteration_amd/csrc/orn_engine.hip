@@ -269,10 +269,22 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
         // online re-parameterisation of every layer (model.py:534): weights only, so all layers up front
         ORN_TRY(orn_launch_merge_group(e->merge_tables, 0, e->merge_tiles[0], st));
         ORN_TRY(orn_launch_merge_group(e->merge_tables, 1, e->merge_tiles[1], st));
+        OrnMergeMisc mm[ORN_MAX_LAYERS];
         for (int i = 0; i < nl; ++i) {
             const orn_layer_desc &l = d.layer[i];
-            ORN_TRY(orn_launch_merge_bias(P + l.b3x3, P + l.b1x3, P + l.b3x1, l.O, e->L[i].bf, st));
+            mm[i] = OrnMergeMisc{};
+            mm[i].C = l.C; mm[i].O = l.O;
+            mm[i].b3x3 = P + l.b3x3; mm[i].b1x3 = P + l.b1x3; mm[i].b3x1 = P + l.b3x1; mm[i].bf = e->L[i].bf;
         }
+        ORN_TRY(orn_launch_merge_bias_all(nl, mm, st));
+    }
+    if (ff < nl) {      // bf16 operand copies of every fast layer's merged kernel, one launch
+        OrnPrepLayer pl[ORN_MAX_LAYERS];
+        for (int i = ff; i < nl; ++i) {
+            const orn_layer_desc &l = d.layer[i];
+            pl[i - ff] = OrnPrepLayer{e->L[i].wf, e->L[i].bf, l.O, l.C, l.s, e->L[i].wb, e->L[i].wd, e->L[i].biasp};
+        }
+        ORN_TRY(orn_launch_prep_weights_bf16_all(nl - ff, pl, st));
     }
     for (int i = 0; i < nl; ++i) {
         const orn_layer_desc &l = d.layer[i];
@@ -282,7 +294,6 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
             x = b.a;
         } else {
             if (i == ff) ORN_TRY(orn_launch_nchw_to_nhwc_pad_bf16(x, l.C, l.H, l.W, b.xpad, st));
-            ORN_TRY(orn_launch_prep_weights_bf16(b.wf, b.bf, l.O, l.C, l.s, b.wb, b.wd, b.biasp, st));
             ORN_TRY(orn_launch_conv_bf16_fwd(b.xpad, b.wb, b.biasp, l.H, l.W, l.C, l.O, l.s, b.zb,
                                              (i + 1 < nl) ? e->L[i + 1].xpad : nullptr, st));
         }
@@ -351,11 +362,16 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         // merge backward of every layer (closed forms): dW3 & dT, then dW2 & dW1, then the slices
         ORN_TRY(orn_launch_merge_group(e->merge_tables, 2, e->merge_tiles[2], st));
         ORN_TRY(orn_launch_merge_group(e->merge_tables, 3, e->merge_tiles[3], st));
+        OrnMergeMisc mm[ORN_MAX_LAYERS];
         for (int i = 0; i < nl; ++i) {
             const orn_layer_desc &l = d.layer[i];
-            ORN_TRY(orn_launch_merge_bwd_tail(G + l.w3x3, G + l.b3x3, l.C, l.O, G + l.w3x3, G + l.b3x3, G + l.w3x1, G + l.b3x1,
-                                              G + l.w1x3, G + l.b1x3, e->L[i].dw1p, G + l.w1, st));
+            mm[i] = OrnMergeMisc{};
+            mm[i].C = l.C; mm[i].O = l.O;
+            mm[i].g = G + l.w3x3; mm[i].dbf = G + l.b3x3; mm[i].dw1p = e->L[i].dw1p;
+            mm[i].d3x1 = G + l.w3x1; mm[i].db3x1 = G + l.b3x1; mm[i].d1x3 = G + l.w1x3; mm[i].db1x3 = G + l.b1x3;
+            mm[i].dw1 = G + l.w1;
         }
+        ORN_TRY(orn_launch_merge_bwd_tail_all(nl, mm, st));
     }
     ORN_TRY(orn_launch_stem_bwd(embeds, fidx, d.embed_len, P + d.stem_w1, e->pre1, e->h1, e->pre2, e->dh2, 1, d.embed_len,
                                 d.stem_dim, Nout, G + d.stem_w0, G + d.stem_b0, G + d.stem_w1, G + d.stem_b1, e->scratch, st));

@@ -40,6 +40,16 @@ int orn_launch_merge_bias(const float *b3x3, const float *b1x3, const float *b3x
 int orn_launch_merge_bwd_tail(const float *g, const float *dbf, int C, int O, float *d3x3, float *db3x3, float *d3x1,
                               float *db3x1, float *d1x3, float *db1x3, const float *dw1p, float *dw1, hipStream_t st);
 
+// per-layer elementwise tails of the merge, all layers per launch
+struct OrnMergeMisc {
+    int C, O;
+    const float *b3x3, *b1x3, *b3x1; float *bf;                       // forward bias
+    const float *g, *dbf, *dw1p;                                      // backward inputs (dWf, dbf live in the grad arena)
+    float *d3x1, *db3x1, *d1x3, *db1x3, *dw1;                         // backward outputs
+};
+int orn_launch_merge_bias_all(int n, const OrnMergeMisc *L, hipStream_t st);
+int orn_launch_merge_bwd_tail_all(int n, const OrnMergeMisc *L, hipStream_t st);
+
 // orn_conv_f32.hip
 int orn_launch_conv3x3_f32(const float *x, const float *w, const float *bias, int B, int C, int O, int H, int W,
                            int s, int epi, float *z, float *out, hipStream_t st, float *split_ws);
@@ -63,6 +73,8 @@ int orn_launch_wgrad_bf16(const h16 *xpad, const h16 *dypad, int H, int W, int C
                           float *slabs, float *dwf, float *dbf, hipStream_t st);
 int orn_launch_prep_weights_bf16(const float *wf, const float *bf, int O, int C, int s, h16 *wb, h16 *wd, float *bias_p,
                                  hipStream_t st);
+struct OrnPrepLayer { const float *wf, *bf; int O, C, s; h16 *wb, *wd; float *biasp; };
+int orn_launch_prep_weights_bf16_all(int n, const OrnPrepLayer *L, hipStream_t st);
 int orn_launch_nchw_to_nhwc_pad_bf16(const float *src, int C, int H, int W, h16 *dst, hipStream_t st);
 int orn_launch_nhwc_to_nchw_f32(const float *src, int C, int H, int W, int nslab, float *dst, hipStream_t st);
 int orn_dgrad_f32_slabs(int H, int W, int O);

@@ -12,6 +12,7 @@
 #define SS_TW 64
 #define SS_PH (SS_TH + 10)
 #define SS_PW (SS_TW + 10)
+#define SS_PWP 76            // padded row stride (floats): 16-byte aligned rows for float4 LDS reads
 
 __constant__ float c_gauss[11];
 
@@ -29,10 +30,12 @@ struct LossP {
     int tiles_w_v, tiles_h_v, tiles_w, tiles_h;
 };
 
+// Register-blocked separable filtering: every thread produces 4 adjacent outputs from a 14-wide window
+// (3x fewer LDS reads than one output per thread).
 __global__ void __launch_bounds__(256) k_ssim_stats(LossP q)
 {
-    __shared__ float Ps[SS_PH][SS_PW];
-    __shared__ float Ts[SS_PH][SS_PW];
+    __shared__ __attribute__((aligned(16))) float Ps[SS_PH][SS_PWP];
+    __shared__ __attribute__((aligned(16))) float Ts[SS_PH][SS_PWP];
     __shared__ float Hs[5][SS_PH][SS_TW];
     __shared__ float sred[16];
     const int t = threadIdx.x;
@@ -42,56 +45,93 @@ __global__ void __launch_bounds__(256) k_ssim_stats(LossP q)
     const size_t HW = (size_t)q.H * q.W;
     const float *pp = q.pred + (size_t)plane * HW;
     const float *tp = q.target + (q.frame_idx ? (size_t)(*q.frame_idx) * q.frame_stride : 0) + (size_t)plane * HW;
-    for (int idx = t; idx < SS_PH * SS_PW; idx += 256) {
-        const int r = idx / SS_PW, c = idx - r * SS_PW;
-        const int gy = y0 + r, gx = x0 + c;
-        float a = 0.f, b = 0.f;
-        if (gy < q.H && gx < q.W) { a = pp[(size_t)gy * q.W + gx]; b = tp[(size_t)gy * q.W + gx]; }
-        Ps[r][c] = a;
-        Ts[r][c] = b;
+    {   // all global loads in flight before the first LDS write
+        constexpr int NL = (SS_PH * SS_PWP + 255) / 256;
+        float ra[NL], rb[NL];
+#pragma unroll
+        for (int it = 0; it < NL; ++it) {
+            const int idx = t + it * 256;
+            const int r = idx / SS_PWP, c = idx - r * SS_PWP;
+            const int gy = y0 + r, gx = x0 + c;
+            ra[it] = 0.f; rb[it] = 0.f;
+            if (idx < SS_PH * SS_PWP && c < SS_PW && gy < q.H && gx < q.W) { ra[it] = pp[(size_t)gy * q.W + gx]; rb[it] = tp[(size_t)gy * q.W + gx]; }
+        }
+#pragma unroll
+        for (int it = 0; it < NL; ++it) {
+            const int idx = t + it * 256;
+            if (idx < SS_PH * SS_PWP) { (&Ps[0][0])[idx] = ra[it]; (&Ts[0][0])[idx] = rb[it]; }
+        }
     }
     __syncthreads();
-    for (int idx = t; idx < SS_PH * SS_TW; idx += 256) {
-        const int r = idx / SS_TW, c = idx - r * SS_TW;
-        float sp = 0.f, st = 0.f, spp = 0.f, stt = 0.f, spt = 0.f;
+    // horizontal pass: item = (row r, 4 columns c4..c4+3)
+    for (int idx = t; idx < SS_PH * (SS_TW / 4); idx += 256) {
+        const int r = idx / (SS_TW / 4), c4 = (idx - r * (SS_TW / 4)) * 4;
+        float a[16], b[16];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float g = c_gauss[k], a = Ps[r][c + k], b = Ts[r][c + k];
-            sp = fmaf(g, a, sp);
-            st = fmaf(g, b, st);
-            spp = fmaf(g, a * a, spp);
-            stt = fmaf(g, b * b, stt);
-            spt = fmaf(g, a * b, spt);
+        for (int k = 0; k < 4; ++k) {
+            const float4 va = *reinterpret_cast<const float4 *>(&Ps[r][c4 + 4 * k]);
+            const float4 vb = *reinterpret_cast<const float4 *>(&Ts[r][c4 + 4 * k]);
+            a[4 * k] = va.x; a[4 * k + 1] = va.y; a[4 * k + 2] = va.z; a[4 * k + 3] = va.w;
+            b[4 * k] = vb.x; b[4 * k + 1] = vb.y; b[4 * k + 2] = vb.z; b[4 * k + 3] = vb.w;
         }
-        Hs[0][r][c] = sp; Hs[1][r][c] = st; Hs[2][r][c] = spp; Hs[3][r][c] = stt; Hs[4][r][c] = spt;
+        float sp[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0}, spp[4] = {0, 0, 0, 0}, stt[4] = {0, 0, 0, 0}, spt[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 14; ++k) {
+            const float aa = a[k] * a[k], bb = b[k] * b[k], ab = a[k] * b[k];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const int tap = k - o;
+                if (tap >= 0 && tap < 11) {
+                    const float g = c_gauss[tap];
+                    sp[o] = fmaf(g, a[k], sp[o]);
+                    st[o] = fmaf(g, b[k], st[o]);
+                    spp[o] = fmaf(g, aa, spp[o]);
+                    stt[o] = fmaf(g, bb, stt[o]);
+                    spt[o] = fmaf(g, ab, spt[o]);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            Hs[0][r][c4 + o] = sp[o]; Hs[1][r][c4 + o] = st[o]; Hs[2][r][c4 + o] = spp[o];
+            Hs[3][r][c4 + o] = stt[o]; Hs[4][r][c4 + o] = spt[o];
+        }
     }
     __syncthreads();
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     float ssum = 0.f;
-    for (int idx = t; idx < SS_TH * SS_TW; idx += 256) {
-        const int r = idx / SS_TW, c = idx - r * SS_TW;
-        const int gy = y0 + r, gx = x0 + c;
-        if (gy >= q.Hv || gx >= q.Wv) continue;
-        float m = 0.f, mu = 0.f, qq = 0.f, tt = 0.f, rr = 0.f;
+    {   // vertical pass: item = (column c, 4 rows r4..r4+3); 256 items = one per thread
+        const int c = t & (SS_TW - 1), r4 = (t / SS_TW) * 4;
+        float v[5][4];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float g = c_gauss[k];
-            m = fmaf(g, Hs[0][r + k][c], m);
-            mu = fmaf(g, Hs[1][r + k][c], mu);
-            qq = fmaf(g, Hs[2][r + k][c], qq);
-            tt = fmaf(g, Hs[3][r + k][c], tt);
-            rr = fmaf(g, Hs[4][r + k][c], rr);
+        for (int m = 0; m < 5; ++m) {
+            float col[14];
+#pragma unroll
+            for (int k = 0; k < 14; ++k) col[k] = Hs[m][r4 + k][c];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; ++k) acc = fmaf(c_gauss[k], col[o + k], acc);
+                v[m][o] = acc;
+            }
         }
-        const float sp = qq - m * m, st = tt - mu * mu, spt = rr - m * mu;
-        const float A1 = 2.f * m * mu + C1, A2 = 2.f * spt + C2;
-        const float B1 = m * m + mu * mu + C1, B2 = sp + st + C2;
-        const float inv = 1.0f / (B1 * B2);
-        const float S = A1 * A2 * inv;
-        ssum += S;
-        const size_t o = ((size_t)plane * q.Hv + gy) * q.Wv + gx;
-        q.dm[o] = 2.f * mu * (A2 - A1) * inv - 2.f * m * S / B1 + 2.f * m * S / B2;
-        q.dq[o] = -S / B2;
-        q.dr[o] = 2.f * A1 * inv;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int gy = y0 + r4 + o, gx = x0 + c;
+            if (gy >= q.Hv || gx >= q.Wv) continue;
+            const float m = v[0][o], mu = v[1][o], qq = v[2][o], tt = v[3][o], rr = v[4][o];
+            const float sp = qq - m * m, st = tt - mu * mu, spt = rr - m * mu;
+            const float A1 = 2.f * m * mu + C1, A2 = 2.f * spt + C2;
+            const float B1 = m * m + mu * mu + C1, B2 = sp + st + C2;
+            const float inv = 1.0f / (B1 * B2);
+            const float S = A1 * A2 * inv;
+            ssum += S;
+            const size_t oo = ((size_t)plane * q.Hv + gy) * q.Wv + gx;
+            q.dm[oo] = 2.f * mu * (A2 - A1) * inv - 2.f * m * S / B1 + 2.f * m * S / B2;
+            q.dq[oo] = -S / B2;
+            q.dr[oo] = 2.f * A1 * inv;
+        }
     }
     const float tot = orn_block_sum(ssum, sred);
     if (t == 0) q.part_ssim[(size_t)plane * gridDim.x + blockIdx.x] = tot;
@@ -99,7 +139,7 @@ __global__ void __launch_bounds__(256) k_ssim_stats(LossP q)
 
 __global__ void __launch_bounds__(256) k_loss_grad(LossP q)
 {
-    __shared__ float Ds[3][SS_PH][SS_PW];
+    __shared__ __attribute__((aligned(16))) float Ds[3][SS_PH][SS_PWP];
     __shared__ float Hh[3][SS_PH][SS_TW];
     __shared__ float sred[16];
     const int t = threadIdx.x;
@@ -112,29 +152,46 @@ __global__ void __launch_bounds__(256) k_loss_grad(LossP q)
     const bool ssim = (q.loss_type == ORN_LOSS_FUSION6);
     if (ssim) {
         const size_t mo = (size_t)plane * q.Hv * q.Wv;
-        for (int idx = t; idx < SS_PH * SS_PW; idx += 256) {
-            const int r = idx / SS_PW, c = idx - r * SS_PW;
-            const int vy = y0 + r - 10, vx = x0 + c - 10;       // valid-map coords
-            float a = 0.f, b = 0.f, d = 0.f;
-            if (vy >= 0 && vy < q.Hv && vx >= 0 && vx < q.Wv) {
-                const size_t o = mo + (size_t)vy * q.Wv + vx;
-                a = q.dm[o]; b = q.dq[o]; d = q.dr[o];
+        {
+            constexpr int NL = (SS_PH * SS_PWP + 255) / 256;
+            float r0[NL], r1[NL], r2[NL];
+#pragma unroll
+            for (int it = 0; it < NL; ++it) {
+                const int idx = t + it * 256;
+                const int r = idx / SS_PWP, c = idx - r * SS_PWP;
+                const int vy = y0 + r - 10, vx = x0 + c - 10;       // valid-map coords
+                r0[it] = 0.f; r1[it] = 0.f; r2[it] = 0.f;
+                if (idx < SS_PH * SS_PWP && c < SS_PW && vy >= 0 && vy < q.Hv && vx >= 0 && vx < q.Wv) {
+                    const size_t o = mo + (size_t)vy * q.Wv + vx;
+                    r0[it] = q.dm[o]; r1[it] = q.dq[o]; r2[it] = q.dr[o];
+                }
             }
-            Ds[0][r][c] = a; Ds[1][r][c] = b; Ds[2][r][c] = d;
+#pragma unroll
+            for (int it = 0; it < NL; ++it) {
+                const int idx = t + it * 256;
+                if (idx < SS_PH * SS_PWP) { (&Ds[0][0][0])[idx] = r0[it]; (&Ds[1][0][0])[idx] = r1[it]; (&Ds[2][0][0])[idx] = r2[it]; }
+            }
         }
         __syncthreads();
         // out[y][x] = sum_{a,b} g[a] g[b] D[y-a][x-b];  patch index of (y-a) is (y_local + 10 - a)
-        for (int idx = t; idx < SS_PH * SS_TW; idx += 256) {
-            const int r = idx / SS_TW, c = idx - r * SS_TW;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int idx = t; idx < SS_PH * (SS_TW / 4); idx += 256) {
+            const int r = idx / (SS_TW / 4), c4 = (idx - r * (SS_TW / 4)) * 4;
 #pragma unroll
-            for (int k = 0; k < 11; ++k) {
-                const float g = c_gauss[k];
-                s0 = fmaf(g, Ds[0][r][c + 10 - k], s0);
-                s1 = fmaf(g, Ds[1][r][c + 10 - k], s1);
-                s2 = fmaf(g, Ds[2][r][c + 10 - k], s2);
+            for (int m = 0; m < 3; ++m) {
+                float w[16];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 v = *reinterpret_cast<const float4 *>(&Ds[m][r][c4 + 4 * k]);
+                    w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+                }
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) acc = fmaf(c_gauss[k], w[o + 10 - k], acc);
+                    Hh[m][r][c4 + o] = acc;
+                }
             }
-            Hh[0][r][c] = s0; Hh[1][r][c] = s1; Hh[2][r][c] = s2;
         }
         __syncthreads();
     }

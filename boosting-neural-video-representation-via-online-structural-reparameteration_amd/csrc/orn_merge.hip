@@ -384,3 +384,72 @@ int orn_launch_merge_bwd_tail(const float *g, const float *dbf, int C, int O, fl
     ORN_LAUNCH_CHECK("merge_bwd_slices");
     return orn_launch_reduce_rows(dw1p, 9, (size_t)2 * C * C, (size_t)2 * C * C, dw1, st);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Per-layer elementwise tails of the merge, all layers in one launch each (blockIdx.y = layer).
+// ------------------------------------------------------------------------------------------------
+struct MiscLayers {
+    int n;
+    OrnMergeMisc l[ORN_MAX_LAYERS];
+};
+
+__global__ void k_merge_bias_all(MiscLayers m)
+{
+    const OrnMergeMisc &l = m.l[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < l.O) l.bf[i] = l.b3x3[i] + (l.b1x3[i] + l.b3x1[i]);     // model.py:476,496
+}
+
+// slices of dWf into the 1x3 / 3x1 branches, bias fan-out, and dW1 = fixed-order sum of its 9 partials
+__global__ void k_merge_bwd_tail_all(MiscLayers m)
+{
+    const OrnMergeMisc &l = m.l[blockIdx.y];
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long OC = (long)l.O * l.C;
+    if (i < OC) {
+        const float *gg = l.g + i * 9;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            l.d1x3[i * 3 + k] = gg[3 + k];
+            l.d3x1[i * 3 + k] = gg[3 * k + 1];
+        }
+    }
+    if (i < l.O) {
+        const float d = l.dbf[i];
+        l.db3x1[i] = d;
+        l.db1x3[i] = d;
+    }
+    const long n1 = (long)2 * l.C * l.C;
+    if (i < n1) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc += l.dw1p[(long)k * n1 + i];
+        l.dw1[i] = acc;
+    }
+}
+
+int orn_launch_merge_bias_all(int n, const OrnMergeMisc *L, hipStream_t st)
+{
+    MiscLayers m;
+    m.n = n;
+    int maxO = 0;
+    for (int i = 0; i < n; ++i) { m.l[i] = L[i]; if (L[i].O > maxO) maxO = L[i].O; }
+    hipLaunchKernelGGL(k_merge_bias_all, dim3(orn_cdiv(maxO, 256), n), dim3(256), 0, st, m);
+    ORN_LAUNCH_CHECK("merge_bias_all");
+    return 0;
+}
+
+int orn_launch_merge_bwd_tail_all(int n, const OrnMergeMisc *L, hipStream_t st)
+{
+    MiscLayers m;
+    m.n = n;
+    long mx = 0;
+    for (int i = 0; i < n; ++i) {
+        m.l[i] = L[i];
+        const long w = (long)L[i].O * L[i].C > (long)2 * L[i].C * L[i].C ? (long)L[i].O * L[i].C : (long)2 * L[i].C * L[i].C;
+        if (w > mx) mx = w;
+    }
+    hipLaunchKernelGGL(k_merge_bwd_tail_all, dim3(orn_cdiv(mx, 256), n), dim3(256), 0, st, m);
+    ORN_LAUNCH_CHECK("merge_bwd_tail_all");
+    return 0;
+}
