@@ -25,18 +25,18 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // 64x64 output tile per work-group, 4 waves (2x2), each wave one 32x32 v_mfma_f32_32x32x2_f32 block.
 // K is consumed in ascending order, 2 per instruction (lane half 0 = even k first, then odd k), the
-// 32-deep chunks in ascending order, always into the same accumulator: one k-ordered fmaf chain per
+// 64-deep chunks in ascending order, always into the same accumulator: one k-ordered fmaf chain per
 // output element, bit-identical to oracle/merge_ref.c.  Out-of-range K is zero-filled
 // (fma(0, 0, acc) == acc).  Next chunk's global loads are issued before the MFMAs of the current one.
 #define GT 64
-#define GK 32
+#define GK 64
 #define GLDA (GK + 1)
 #define GLDB (GT + 4)
 
 __device__ __forceinline__ void gemm_body(const GemmP &p, int bx, int by, int bz)
 {
-    __shared__ float As[2][GT][GLDA];
-    __shared__ float Bs[2][GK][GLDB];
+    __shared__ float As[GT][GLDA];
+    __shared__ float Bs[GK][GLDB];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
@@ -48,50 +48,52 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, int bx, int by, int bz
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    float ra[8], rb[8];
+    // per-thread element coordinates inside a 64x64 tile (16 A + 16 B elements), loop invariant
+    constexpr int NE = GT * GK / 256;
+    float ra[NE], rb[NE];
+    long aoff[NE], boff[NE];
+    int alds[NE], blds[NE];
+    bool aok[NE], bok[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        int kk, m;
+        if (p.a_kfast) { kk = t & 63; m = (t >> 6) + 4 * i; }
+        else           { m = t & 63;  kk = (t >> 6) + 4 * i; }
+        aoff[i] = (long)(m0 + m) * p.sam + (long)kk * p.sak;
+        alds[i] = m * GLDA + kk;
+        aok[i] = (m0 + m) < p.M;
+        int kb, n;
+        if (p.b_nfast) { n = t & 63;  kb = (t >> 6) + 4 * i; }
+        else           { kb = t & 63; n = (t >> 6) + 4 * i; }
+        boff[i] = (long)kb * p.sbk + (long)(n0 + n) * p.sbn;
+        blds[i] = kb * GLDB + n;
+        bok[i] = (n0 + n) < p.N;
+    }
+    // kk / kb of element i (needed for the K bound)
+    auto kk_of = [&](int i) { return p.a_kfast ? (t & 63) : (t >> 6) + 4 * i; };
+    auto kb_of = [&](int i) { return p.b_nfast ? (t >> 6) + 4 * i : (t & 63); };
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int kk, m;
-            if (p.a_kfast) { kk = t & 31; m = (t >> 5) + 8 * i; }
-            else           { m = t & 63;  kk = (t >> 6) + 4 * i; }
-            const int gm = m0 + m, gk = k0 + kk;
-            ra[i] = (gm < p.M && gk < p.K) ? A[(long)gm * p.sam + (long)gk * p.sak] : 0.f;
-            int kb, n;
-            if (p.b_nfast) { n = t & 63;  kb = (t >> 6) + 4 * i; }
-            else           { kb = t & 31; n = (t >> 5) + 8 * i; }
-            const int gn = n0 + n, gkb = k0 + kb;
-            rb[i] = (gn < p.N && gkb < p.K) ? B[(long)gkb * p.sbk + (long)gn * p.sbn] : 0.f;
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int kk, m;
-            if (p.a_kfast) { kk = t & 31; m = (t >> 5) + 8 * i; }
-            else           { m = t & 63;  kk = (t >> 6) + 4 * i; }
-            As[buf][m][kk] = ra[i];
-            int kb, n;
-            if (p.b_nfast) { n = t & 63;  kb = (t >> 6) + 4 * i; }
-            else           { kb = t & 31; n = (t >> 5) + 8 * i; }
-            Bs[buf][kb][n] = rb[i];
+        for (int i = 0; i < NE; ++i) {
+            ra[i] = (aok[i] && k0 + kk_of(i) < p.K) ? A[aoff[i] + (long)k0 * p.sak] : 0.f;
+            rb[i] = (bok[i] && k0 + kb_of(i) < p.K) ? B[boff[i] + (long)k0 * p.sbk] : 0.f;
         }
     };
     gload(0);
-    lstore(0);
-    __syncthreads();
-    int cur = 0;
     for (int k0 = 0; k0 < p.K; k0 += GK) {
-        const bool has_next = (k0 + GK < p.K);
-        if (has_next) gload(k0 + GK);
-        const float *ap = &As[cur][wm * 32 + l31][hh];
-        const float *bp = &Bs[cur][hh][wn * 32 + l31];
+        __syncthreads();                       // everyone is done reading the previous chunk
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            (&As[0][0])[alds[i]] = ra[i];
+            (&Bs[0][0])[blds[i]] = rb[i];
+        }
+        __syncthreads();
+        if (k0 + GK < p.K) gload(k0 + GK);     // next chunk's loads fly under this chunk's 32 MFMAs
+        const float *ap = &As[wm * 32 + l31][hh];
+        const float *bp = &Bs[hh][wn * 32 + l31];
 #pragma unroll
         for (int kk = 0; kk < GK; kk += 2)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk * GLDB], acc, 0, 0, 0);
-        if (has_next) lstore(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
     }
     const int gn = n0 + wn * 32 + l31;
     if (gn >= p.N) return;
