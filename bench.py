@@ -89,20 +89,22 @@ def conv_roofline(eng, precision, iters=10):
     for li, L in enumerate(geo):
         C, O, s, H, W = L['C'], L['O'], L['s'], L['H'], L['W']
         st = _lib.stream()
-        if precision == 'bf16':
+        if precision in ('bf16', 'fp16'):
             if C != 96:
                 continue
             Cn = O // (s * s)
-            xpad = torch.zeros(H + 2, W + 2, C, device=dev, dtype=torch.bfloat16)
-            xpad[1:-1, 1:-1] = torch.randn(H, W, C, device=dev).to(torch.bfloat16)
-            wb = (torch.randn(9, O, C, device=dev) * (1.0 / (9 * C) ** 0.5)).to(torch.bfloat16)
+            hdt = torch.bfloat16 if precision == 'bf16' else torch.float16
+            fwd = lib.orn_conv_nhwc_bf16_fwd if precision == 'bf16' else lib.orn_conv_nhwc_f16_fwd
+            xpad = torch.zeros(H + 2, W + 2, C, device=dev, dtype=hdt)
+            xpad[1:-1, 1:-1] = torch.randn(H, W, C, device=dev).to(hdt)
+            wb = (torch.randn(9, O, C, device=dev) * (1.0 / (9 * C) ** 0.5)).to(hdt)
             bp = torch.zeros(O, device=dev)
-            z = torch.empty(H * s, W * s, Cn, device=dev, dtype=torch.bfloat16)
-            apad = torch.zeros(H * s + 2, W * s + 2, Cn, device=dev, dtype=torch.bfloat16) if li + 1 < len(geo) else None
+            z = torch.empty(H * s, W * s, Cn, device=dev, dtype=hdt)
+            apad = torch.zeros(H * s + 2, W * s + 2, Cn, device=dev, dtype=hdt) if li + 1 < len(geo) else None
             keep = (xpad, wb, bp, z, apad)
 
             def run():
-                _lib.check(lib.orn_conv_nhwc_bf16_fwd(c_void_p(xpad.data_ptr()), c_void_p(wb.data_ptr()), _lib.ptr(bp), H, W, C, O, s,
+                _lib.check(fwd(c_void_p(xpad.data_ptr()), c_void_p(wb.data_ptr()), _lib.ptr(bp), H, W, C, O, s,
                                                       c_void_p(z.data_ptr()), c_void_p(apad.data_ptr()) if apad is not None else None, st))
         else:
             x = torch.randn(1, C, H, W, device=dev)
@@ -133,7 +135,7 @@ def conv_roofline(eng, precision, iters=10):
     return tot_f / n, tot_t / n, per_layer
 
 
-def cpu_baseline(steps=2):
+def cpu_baseline(steps=8):
     """The CPU oracle ("port": same ATen CPU ops as the reference's CPU path) timed on this host,
     bounded sample: 1 warm-up + `steps` ERB training steps at 720p with Fusion6."""
     from oracle import cpu_ref
@@ -161,7 +163,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=264)
     ap.add_argument('--warmup', type=int, default=66)
-    ap.add_argument('--precision', default=os.environ.get('ORN_PRECISION', 'bf16'), choices=['fp32', 'bf16'])
+    ap.add_argument('--precision', default=os.environ.get('ORN_PRECISION', 'fp16'), choices=['fp32', 'bf16', 'fp16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     args = ap.parse_args()
@@ -204,13 +206,13 @@ def main():
 
     if rank == 0:
         fl, avg_dt, per_layer = conv_roofline(eng, args.precision)
-        peak = 157.3 if args.precision == 'fp32' else 2500.0
+        peak = 157.3 if args.precision == 'fp32' else 2500.0      # fp32 MFMA / dense 16-bit MFMA (bf16 and f16 share the rate)
         achieved = fl / avg_dt / 1e12
         out = {
             'metric': 'training frames/sec, Bunny 720p ERB', 'value': world * args.steps / dt, 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.precision == 'fp32' else 'bf16', 'data': 'synthetic',
+            'dtype': {'fp32': 'f32', 'bf16': 'bf16', 'fp16': 'f16'}[args.precision], 'data': 'synthetic',
             'config': {'workload': 'configs[1]: Bunny-shaped 132x3x720x1280 synthetic video, branch_type=ERB, fc_hw_dim 9_16_26, '
                                    'strides 5 2 2 2 2, stem 512_1, lower_width 96, Fusion6, Adam(0.5,0.999), b=1; '
                                    'one independent video per GPU', 'precision': args.precision, 'hip_graph': graph,
@@ -219,7 +221,7 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                          'traffic': None,
                          'kernel': ('k_conv3x3_f32<EPI_PS_SILU> (5 launches/step, L0..L4)' if args.precision == 'fp32'
-                                    else 'k_conv_nhwc_bf16<4,2,2,2,EPI_B_FWD> (3 launches/step, L2..L4)'),
+                                    else f'orn_{"bf16" if args.precision == "bf16" else "f16"}::k_conv_nhwc_bf16<4,2,2,2,EPI_B_FWD> (3 launches/step, L2..L4)'),
                          'flops_per_launch': fl, 'avg_launch_ms': avg_dt * 1e3, 'per_layer': per_layer},
         }
         if not args.no_cpu_baseline and world == 1:

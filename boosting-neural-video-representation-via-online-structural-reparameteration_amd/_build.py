@@ -26,15 +26,21 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hm = _deps_mtime()
     jobs = []
+    objs = []
     for src in _sources():
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src[:-4] + '.o')
-        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hm):
-            jobs.append((s, o))
+        variants = [('', [])]
+        if src == 'orn_conv_bf16.hip':            # the 16-bit fast path is built for bf16 and for IEEE half
+            variants.append(('_f16', ['-DORN_FP16']))
+        for suffix, extra in variants:
+            o = os.path.join(OBJ, src[:-4] + suffix + '.o')
+            objs.append(o)
+            if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hm):
+                jobs.append((s, o, extra))
 
     def cc(job):
-        s, o = job
-        cmd = [HIPCC] + FLAGS + ['-c', s, '-o', o]
+        s, o, extra = job
+        cmd = [HIPCC] + FLAGS + extra + ['-c', s, '-o', o]
         if verbose:
             print(' '.join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -47,7 +53,6 @@ def build(force: bool = False, verbose: bool = False) -> str:
             for warn in ex.map(cc, jobs):
                 if warn and verbose:
                     print(warn, file=sys.stderr)
-    objs = [os.path.join(OBJ, s[:-4] + '.o') for s in _sources()]
     if jobs or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

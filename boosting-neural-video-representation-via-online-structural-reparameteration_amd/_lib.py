@@ -49,6 +49,7 @@ _SIGS = {
     'orn_conv3x3_ps_silu_fwd_bf16': (c_int, [P, P, P] + [c_int] * 5 + [P, P, P, c_size_t, P]),
     'orn_conv3x3_ps_silu_bwd_bf16': (c_int, [P, P, P, P] + [c_int] * 5 + [P, P, P, P, c_size_t, P]),
     'orn_conv_nhwc_bf16_fwd': (c_int, [P, P, P] + [c_int] * 5 + [P, P, P]),
+    'orn_conv_nhwc_f16_fwd': (c_int, [P, P, P] + [c_int] * 5 + [P, P, P]),
     'orn_dgrad_nhwc_bf16': (c_int, [P, P] + [c_int] * 4 + [P, P, c_int, P]),
     'orn_wgrad_nhwc_bf16_ws_bytes': (c_size_t, [c_int] * 3),
     'orn_wgrad_nhwc_bf16': (c_int, [P, P] + [c_int] * 5 + [P, P, P, P]),

@@ -14,17 +14,27 @@
 // read 1.33x instead of 9x -- while [BN][96] weight tiles stream from L2 through a double-buffered
 // LDS stage.  wgrad: work-group = 128 out channels x one kernel row (3 taps) x all 96 in-channels,
 // K = pixels, both operands pixel-major in LDS and read with ds_read_b64_tr_b16.
-#include "orn_common.h"
-
+// This file is compiled twice: as is (bf16, namespace orn_bf16) and with -DORN_FP16 (IEEE half, namespace
+// orn_f16: 11-bit significand, same MFMA rate; gradients then travel scaled by 2^20, see the engine).
+#include "orn_internal.h"
+#ifdef ORN_FP16
+#define HNS orn_f16
+typedef _Float16 h16;
+#define MFMA_H16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#else
+#define HNS orn_bf16
 typedef __bf16 h16;
-typedef __attribute__((ext_vector_type(8))) __bf16 h16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 h16x4;
+#define MFMA_H16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
+typedef __attribute__((ext_vector_type(8))) h16 h16x8;
+typedef __attribute__((ext_vector_type(4))) h16 h16x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
+namespace HNS {
+
 static int g_conv_dbg = 0;   // timing experiments only (tools/probes), see orn_debug_set
-#define MFMA_H16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
 #define CB_TH 8
 #define CB_TW 32
@@ -37,7 +47,7 @@ static int g_conv_dbg = 0;   // timing experiments only (tools/probes), see orn_
 
 enum { EPI_B_FWD = 0, EPI_B_DGRAD = 1, EPI_B_DGRAD_F32 = 2 };
 
-typedef __attribute__((ext_vector_type(2))) __bf16 h16x2;
+typedef __attribute__((ext_vector_type(2))) h16 h16x2;
 __device__ __forceinline__ unsigned pack_h16x2(float lo, float hi)
 {
     h16x2 v;
@@ -367,7 +377,7 @@ static int launch_conv_cfg(const ConvBP &p, int n_tiles_total, hipStream_t st)
     return 0;
 }
 
-extern "C" void orn_debug_set(int flags) { g_conv_dbg = flags; }   // timing experiments only (tools/probes)
+void set_debug(int flags) { g_conv_dbg = flags; }
 
 // fwd: N tile 128 (waves 4x2, wave tile 64 px x 64 ch); dgrad: N = 96 in one tile (waves 8x1, 32 px x 96 ch)
 int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p, int H, int W, int Cin, int O, int s,
@@ -666,7 +676,6 @@ __global__ void k_prep_weights_bf16(const float *__restrict__ wf, const float *_
     wd[((size_t)(8 - tap) * C + c) * O + op] = v;
 }
 
-struct OrnPrepLayer { const float *wf, *bf; int O, C, s; __bf16 *wb, *wd; float *biasp; };
 struct PrepAll {
     int n;
     struct { const float *wf, *bf; int O, C, Cn, s2; h16 *wb, *wd; float *biasp; } l[ORN_MAX_LAYERS];
@@ -699,7 +708,7 @@ int orn_launch_prep_weights_bf16_all(int n, const OrnPrepLayer *L, hipStream_t s
     for (int i = 0; i < n; ++i) {
         a.l[i].wf = L[i].wf; a.l[i].bf = L[i].bf; a.l[i].O = L[i].O; a.l[i].C = L[i].C;
         a.l[i].Cn = L[i].O / (L[i].s * L[i].s); a.l[i].s2 = L[i].s * L[i].s;
-        a.l[i].wb = L[i].wb; a.l[i].wd = L[i].wd; a.l[i].biasp = L[i].biasp;
+        a.l[i].wb = (h16 *)L[i].wb; a.l[i].wd = (h16 *)L[i].wd; a.l[i].biasp = L[i].biasp;
         const size_t w = (size_t)L[i].O * L[i].C * 9;
         if (w > mx) mx = w;
     }
@@ -742,7 +751,8 @@ __global__ void __launch_bounds__(256) k_nchw_to_nhwc_pad_bf16(const float *__re
 }
 
 // fp32 NHWC slabs [nslab][H][W][C] -> fp32 NCHW [C][H][W] (sum over slabs in fixed order), tiled through LDS
-__global__ void __launch_bounds__(256) k_nhwc_to_nchw_f32(const float *__restrict__ src, int C, int H, int W, int nslab, float *__restrict__ dst)
+__global__ void __launch_bounds__(256) k_nhwc_to_nchw_f32(const float *__restrict__ src, int C, int H, int W, int nslab, float scale,
+                                                         float *__restrict__ dst)
 {
     __shared__ float tile[TR_MAXC][TR_PX + 1];
     const size_t HW = (size_t)H * W, n = HW * C;
@@ -752,7 +762,7 @@ __global__ void __launch_bounds__(256) k_nhwc_to_nchw_f32(const float *__restric
         float v = 0.f;
         if (p0 + px < HW)
             for (int s = 0; s < nslab; ++s) v += src[(size_t)s * n + (p0 + px) * C + c];
-        tile[c][px] = v;
+        tile[c][px] = v * scale;
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < C * TR_PX; idx += 256) {
@@ -769,10 +779,10 @@ int orn_launch_nchw_to_nhwc_pad_bf16(const float *src, int C, int H, int W, h16 
     return 0;
 }
 
-int orn_launch_nhwc_to_nchw_f32(const float *src, int C, int H, int W, int nslab, float *dst, hipStream_t st)
+int orn_launch_nhwc_to_nchw_f32(const float *src, int C, int H, int W, int nslab, float scale, float *dst, hipStream_t st)
 {
     ORN_REQUIRE(C <= TR_MAXC, "nhwc_to_nchw: C=%d > %d", C, TR_MAXC);
-    hipLaunchKernelGGL(k_nhwc_to_nchw_f32, dim3(orn_cdiv((long)H * W, TR_PX)), dim3(256), 0, st, src, C, H, W, nslab, dst);
+    hipLaunchKernelGGL(k_nhwc_to_nchw_f32, dim3(orn_cdiv((long)H * W, TR_PX)), dim3(256), 0, st, src, C, H, W, nslab, scale, dst);
     ORN_LAUNCH_CHECK("nhwc_to_nchw_f32");
     return 0;
 }
@@ -876,7 +886,7 @@ k_head_fwd_nhwc_bf16(const h16 *__restrict__ z, const float *__restrict__ w, con
 template <int NQ>
 __global__ void __launch_bounds__(256)
 k_head_bwd_nhwc_bf16(const h16 *__restrict__ z, const float *__restrict__ w, const float *__restrict__ out,
-                     const float *__restrict__ dout, int H, int W, int sigmoid, int sp, h16 *__restrict__ dypad,
+                     const float *__restrict__ dout, int H, int W, int sigmoid, int sp, float gs_up, h16 *__restrict__ dypad,
                      float *__restrict__ partial)
 {
     constexpr int C = NQ * 32;
@@ -898,7 +908,7 @@ k_head_bwd_nhwc_bf16(const h16 *__restrict__ z, const float *__restrict__ w, con
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float o = out[(size_t)k * HW + pix], g = dout[(size_t)k * HW + pix];
-            du[k] = g * (sigmoid ? o * (1.0f - o) : 2.0f * o * (1.0f - o));
+            du[k] = g * gs_up * (sigmoid ? o * (1.0f - o) : 2.0f * o * (1.0f - o));
             dbacc[k] += du[k];
         }
         const int h = (int)(pix / W), ww = (int)(pix - (size_t)h * W);
@@ -976,8 +986,9 @@ int orn_launch_head_fwd_bf16(const h16 *z, const float *w, const float *b, int C
 
 size_t orn_head_bwd_bf16_ws_floats(int C) { return (size_t)(HB_BLOCKS + 1) * (3 * C + 3); }
 
+// gs_up: gradient scale carried by dypad (1 for bf16, 2^20 for fp16); dw/db are un-scaled here
 int orn_launch_head_bwd_bf16(const h16 *z, const float *w, const float *out, const float *dout, int C, int H, int W, int sigmoid,
-                             int sp, float gscale, h16 *dypad, float *dw, float *db, float *ws, hipStream_t st)
+                             int sp, float gs_up, h16 *dypad, float *dw, float *db, float *ws, hipStream_t st)
 {
     ORN_REQUIRE(C == 96 || C == 32 || C == 64 || C == 128, "head_bwd_bf16: unsupported C=%d", C);
     ORN_REQUIRE(H % sp == 0 && W % sp == 0, "head_bwd_bf16: H,W not divisible by stride");
@@ -985,19 +996,41 @@ int orn_launch_head_bwd_bf16(const h16 *z, const float *w, const float *out, con
     if (blocks > HB_BLOCKS) blocks = HB_BLOCKS;
     float *partial = ws, *red = ws + (size_t)HB_BLOCKS * (3 * C + 3);
     switch (C) {
-    case 32: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<1>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, dypad, partial); break;
-    case 64: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<2>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, dypad, partial); break;
-    case 96: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<3>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, dypad, partial); break;
-    default: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<4>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, dypad, partial); break;
+    case 32: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<1>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, gs_up, dypad, partial); break;
+    case 64: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<2>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, gs_up, dypad, partial); break;
+    case 96: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<3>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, gs_up, dypad, partial); break;
+    default: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<4>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, gs_up, dypad, partial); break;
     }
     ORN_LAUNCH_CHECK("head_bwd_bf16");
     const size_t n = 3 * (size_t)C + 3;
     ORN_TRY(orn_launch_reduce_rows(partial, blocks, n, n, red, st));
-    hipLaunchKernelGGL(k_head_bf16_finish, dim3(orn_cdiv((long)n, 128)), dim3(128), 0, st, red, C, gscale, dw, db);
+    hipLaunchKernelGGL(k_head_bf16_finish, dim3(orn_cdiv((long)n, 128)), dim3(128), 0, st, red, C, 1.0f / gs_up, dw, db);
     ORN_LAUNCH_CHECK("head_bf16_finish");
     return 0;
 }
 
+// ---- type-erased operation table for the engine (one per compiled element type) -----------------------
+static int a_conv_fwd(const void *xpad, const void *wb, const float *bias_p, int H, int W, int Cin, int O, int s, void *z, void *apad,
+                      hipStream_t st)
+{ return orn_launch_conv_bf16_fwd((const h16 *)xpad, (const h16 *)wb, bias_p, H, W, Cin, O, s, (h16 *)z, (h16 *)apad, st); }
+static int a_conv_dgrad(const void *dypad, const void *wd, int H, int W, int O, int C, const void *zprev, void *dyprev, int sp,
+                        float *dx_f32, hipStream_t st)
+{ return orn_launch_conv_bf16_dgrad((const h16 *)dypad, (const h16 *)wd, H, W, O, C, (const h16 *)zprev, (h16 *)dyprev, sp, dx_f32, st); }
+static int a_wgrad(const void *xpad, const void *dypad, int H, int W, int C, int O, int s, float gscale, float *slabs, float *dwf,
+                   float *dbf, hipStream_t st)
+{ return orn_launch_wgrad_bf16((const h16 *)xpad, (const h16 *)dypad, H, W, C, O, s, gscale, slabs, dwf, dbf, st); }
+static int a_to_nhwc(const float *src, int C, int H, int W, void *dst, hipStream_t st)
+{ return orn_launch_nchw_to_nhwc_pad_bf16(src, C, H, W, (h16 *)dst, st); }
+static int a_head_fwd(const void *z, const float *w, const float *b, int C, size_t HW, int sigmoid, float *out, hipStream_t st)
+{ return orn_launch_head_fwd_bf16((const h16 *)z, w, b, C, HW, sigmoid, out, st); }
+static int a_head_bwd(const void *z, const float *w, const float *out, const float *dout, int C, int H, int W, int sigmoid, int sp,
+                      float gs_up, void *dypad, float *dw, float *db, float *ws, hipStream_t st)
+{ return orn_launch_head_bwd_bf16((const h16 *)z, w, out, dout, C, H, W, sigmoid, sp, gs_up, (h16 *)dypad, dw, db, ws, st); }
+
+const OrnHalfOps ops = {a_conv_fwd, a_conv_dgrad, orn_wgrad_bf16_ws_floats, a_wgrad, orn_launch_prep_weights_bf16_all, a_to_nhwc,
+                        orn_launch_nhwc_to_nchw_f32, orn_dgrad_f32_slabs, a_head_fwd, orn_head_bwd_bf16_ws_floats, a_head_bwd};
+
+#ifndef ORN_FP16
 // ================================================================================================
 // test / per-op hooks: the bf16 block on PyTorch-layout fp32 tensors (conversions included)
 // ================================================================================================
@@ -1112,7 +1145,7 @@ extern "C" int orn_conv3x3_ps_silu_bwd_bf16(const float *x, const float *wf, con
     ORN_TRY(orn_launch_wgrad_bf16(b.xpad, b.dypad, H, W, C, O, s, 1.0f, b.slabs, dwf, dbf, st));
     if (dx) {
         ORN_TRY(orn_launch_conv_bf16_dgrad(b.dypad, b.wd, H, W, O, C, nullptr, nullptr, 1, b.dxn, st));
-        ORN_TRY(orn_launch_nhwc_to_nchw_f32(b.dxn, C, H, W, orn_dgrad_f32_slabs(H, W, O), dx, st));
+        ORN_TRY(orn_launch_nhwc_to_nchw_f32(b.dxn, C, H, W, orn_dgrad_f32_slabs(H, W, O), 1.0f, dx, st));
     }
     return 0;
 }
@@ -1137,4 +1170,19 @@ extern "C" int orn_dgrad_nhwc_bf16(const void *dypad, const void *wd, int H, int
 {
     return orn_launch_conv_bf16_dgrad((const h16 *)dypad, (const h16 *)wd, H, W, O, C, (const h16 *)zprev, (h16 *)dyprev, sp,
                                       nullptr, (hipStream_t)stream);
+}
+
+extern "C" void orn_debug_set(int flags) { set_debug(flags); }   // timing experiments only (tools/probes)
+#endif  // !ORN_FP16
+
+}  // namespace HNS
+
+const OrnHalfOps *
+#ifdef ORN_FP16
+orn_half_ops_f16()
+#else
+orn_half_ops_bf16()
+#endif
+{
+    return &HNS::ops;
 }

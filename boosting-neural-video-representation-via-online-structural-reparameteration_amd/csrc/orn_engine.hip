@@ -12,10 +12,10 @@ struct LayerBuf {
     float *z, *a;         // block output (pre-activation, activation)          [fp32 layers]
     float *da;            // gradient wrt the block output                       [fp32 layers]
     // bf16 fast path (precision 1, layers >= ff): channels-last bf16, see orn_conv_bf16.hip
-    h16 *xpad;            // conv input, zero-bordered [H+2][W+2][C]
-    h16 *zb;              // pre-activation [Hs][Ws][Cn]
-    h16 *dypad;           // gradient wrt conv output, zero-bordered [H+2][W+2][O'] 
-    h16 *wb, *wd;         // merged kernel in bf16: forward / dgrad operand layouts
+    uint16_t *xpad;       // conv input, zero-bordered [H+2][W+2][C]   (16-bit elements: bf16 or fp16)
+    uint16_t *zb;         // pre-activation [Hs][Ws][Cn]
+    uint16_t *dypad;      // gradient wrt conv output, zero-bordered [H+2][W+2][O']
+    uint16_t *wb, *wd;    // merged kernel in 16 bit: forward / dgrad operand layouts
     float *biasp;         // bias in o' order
 };
 
@@ -31,6 +31,8 @@ struct orn_engine {
     OrnStepCur *cur;                 // state of the step in flight (device)
     LayerBuf L[ORN_MAX_LAYERS];
     int Hout, Wout, Cn_last;
+    const OrnHalfOps *ops;           // 16-bit fast-path kernels (bf16 or fp16 build)
+    float gs;                        // gradient scale carried by the 16-bit gradient tensors (1 for bf16, 2^20 for fp16)
     void *merge_tables;              // device-resident grouped-GEMM problem tables (ERB)
     int merge_tiles[4];
     int ff;                          // first layer on the bf16 fast path (== n_layers: none)
@@ -54,7 +56,7 @@ static int check_desc(const orn_engine_desc *d)
 {
     ORN_REQUIRE(d, "engine: null desc");
     ORN_REQUIRE(d->n_layers >= 1 && d->n_layers <= ORN_MAX_LAYERS, "engine: n_layers=%d out of range", d->n_layers);
-    ORN_REQUIRE(d->precision == 0 || d->precision == 1, "engine: precision %d not built", d->precision);
+    ORN_REQUIRE(d->precision >= 0 && d->precision <= 2, "engine: precision %d not built", d->precision);
     ORN_REQUIRE(d->embed_len > 0 && d->stem_dim > 0 && d->fc_h > 0 && d->fc_w > 0 && d->fc_dim > 0, "engine: bad stem geometry");
     int C = d->fc_dim, H = d->fc_h, W = d->fc_w;
     for (int i = 0; i < d->n_layers; ++i) {
@@ -82,7 +84,7 @@ static bool layer_is_fast(const orn_layer_desc &l)
 // First layer from which every layer (and the head) can run on the bf16 MFMA path.
 static int first_fast_layer(const orn_engine_desc *d)
 {
-    if (d->precision != 1) return d->n_layers;
+    if (d->precision == 0) return d->n_layers;
     const orn_layer_desc &last = d->layer[d->n_layers - 1];
     const int cn = last.O / (last.s * last.s);
     if (!(cn == 32 || cn == 64 || cn == 96 || cn == 128)) return d->n_layers;
@@ -118,14 +120,15 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
             s1 = orn_conv3x3_ps_silu_bwd_ws_bytes(1, l.C, l.O, l.H, l.W) / 4;
         } else {
             // halfs are carved as floats (2 per float)
-            L[i].xpad = (h16 *)take(((size_t)(l.H + 2) * (l.W + 2) * l.C + 1) / 2);
-            L[i].zb = (h16 *)take((asz + 1) / 2);
-            L[i].dypad = (h16 *)take(((size_t)(l.H + 2) * (l.W + 2) * l.O + 1) / 2);
-            L[i].wb = (h16 *)take((wsz + 1) / 2);
-            L[i].wd = (h16 *)take((wsz + 1) / 2);
+            L[i].xpad = (uint16_t *)take(((size_t)(l.H + 2) * (l.W + 2) * l.C + 1) / 2);
+            L[i].zb = (uint16_t *)take((asz + 1) / 2);
+            L[i].dypad = (uint16_t *)take(((size_t)(l.H + 2) * (l.W + 2) * l.O + 1) / 2);
+            L[i].wb = (uint16_t *)take((wsz + 1) / 2);
+            L[i].wd = (uint16_t *)take((wsz + 1) / 2);
             L[i].biasp = take(l.O);
-            if (i == ff) dxn = take((size_t)l.H * l.W * l.C * orn_dgrad_f32_slabs(l.H, l.W, l.O));
-            s1 = al(orn_wgrad_bf16_ws_floats(l.H, l.W, l.O)) + al(orn_dbias_bf16_ws_floats(l.H, l.O));
+            const OrnHalfOps *ops = orn_half_ops_bf16();     // sizes do not depend on the element type
+            if (i == ff) dxn = take((size_t)l.H * l.W * l.C * ops->dgrad_f32_slabs(l.H, l.W, l.O));
+            s1 = al(ops->wgrad_ws_floats(l.H, l.W, l.O));
         }
         if (d->erb) { const size_t s2 = orn_erb_merge_bwd_ws_bytes(l.C, l.O) / 4; if (s2 > s1) s1 = s2; }
         if (s1 > scratch) scratch = s1;
@@ -133,7 +136,7 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
     const size_t isz = (size_t)3 * H * W;
     float *img = take(isz), *dimg = take(isz), *stats = take(8);
     float *loss_ws = take(orn_loss_ws_bytes(1, 3, H, W) / 4);
-    const size_t s3 = (ff < d->n_layers) ? orn_head_bwd_bf16_ws_floats(Cn) : orn_head_bwd_ws_bytes(1, Cn, H, W) / 4;
+    const size_t s3 = (ff < d->n_layers) ? orn_half_ops_bf16()->head_bwd_ws_floats(Cn) : orn_head_bwd_ws_bytes(1, Cn, H, W) / 4;
     if (s3 > scratch) scratch = s3;
     float *scr = take(scratch);
     float *cur = take(16);
@@ -175,6 +178,8 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
     e->params = params; e->grads = grads; e->m = adam_m; e->v = adam_v;
     e->ws = (float *)ws;
     e->graph = nullptr; e->graph_exec = nullptr;
+    e->ops = (d->precision == 2) ? orn_half_ops_f16() : orn_half_ops_bf16();
+    e->gs = (d->precision == 2) ? 1048576.0f : 1.0f;
     layout(d, e);
     {   // the one-pixel borders of the channels-last buffers must be (and stay) zero
         hipError_t rc = hipMemset(ws, 0, need);
@@ -284,7 +289,7 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
             const orn_layer_desc &l = d.layer[i];
             pl[i - ff] = OrnPrepLayer{e->L[i].wf, e->L[i].bf, l.O, l.C, l.s, e->L[i].wb, e->L[i].wd, e->L[i].biasp};
         }
-        ORN_TRY(orn_launch_prep_weights_bf16_all(nl - ff, pl, st));
+        ORN_TRY(e->ops->prep_all(nl - ff, pl, st));
     }
     for (int i = 0; i < nl; ++i) {
         const orn_layer_desc &l = d.layer[i];
@@ -293,14 +298,12 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
             ORN_TRY(orn_launch_conv3x3_f32(x, b.wf, b.bf, 1, l.C, l.O, l.H, l.W, l.s, 1, keep_z ? b.z : nullptr, b.a, st, nullptr));
             x = b.a;
         } else {
-            if (i == ff) ORN_TRY(orn_launch_nchw_to_nhwc_pad_bf16(x, l.C, l.H, l.W, b.xpad, st));
-            ORN_TRY(orn_launch_conv_bf16_fwd(b.xpad, b.wb, b.biasp, l.H, l.W, l.C, l.O, l.s, b.zb,
-                                             (i + 1 < nl) ? e->L[i + 1].xpad : nullptr, st));
+            if (i == ff) ORN_TRY(e->ops->to_nhwc(x, l.C, l.H, l.W, b.xpad, st));
+            ORN_TRY(e->ops->conv_fwd(b.xpad, b.wb, b.biasp, l.H, l.W, l.C, l.O, l.s, b.zb, (i + 1 < nl) ? e->L[i + 1].xpad : nullptr, st));
         }
     }
     if (ff < nl)
-        ORN_TRY(orn_launch_head_fwd_bf16(e->L[nl - 1].zb, P + d.head_w, P + d.head_b, e->Cn_last, (size_t)e->Hout * e->Wout,
-                                         d.sigmoid, e->img, st));
+        ORN_TRY(e->ops->head_fwd(e->L[nl - 1].zb, P + d.head_w, P + d.head_b, e->Cn_last, (size_t)e->Hout * e->Wout, d.sigmoid, e->img, st));
     else
         ORN_TRY(orn_launch_head_fwd(x, P + d.head_w, P + d.head_b, 1, e->Cn_last, (size_t)e->Hout * e->Wout, d.sigmoid, e->img, st));
     return 0;
@@ -335,8 +338,8 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
     }
     const int nl = d.n_layers, ff = e->ff;
     if (ff < nl)
-        ORN_TRY(orn_launch_head_bwd_bf16(e->L[nl - 1].zb, P + d.head_w, e->img, e->dimg, e->Cn_last, e->Hout, e->Wout, d.sigmoid,
-                                         d.layer[nl - 1].s, 1.0f, e->L[nl - 1].dypad, G + d.head_w, G + d.head_b, e->scratch, st));
+        ORN_TRY(e->ops->head_bwd(e->L[nl - 1].zb, P + d.head_w, e->img, e->dimg, e->Cn_last, e->Hout, e->Wout, d.sigmoid,
+                                 d.layer[nl - 1].s, e->gs, e->L[nl - 1].dypad, G + d.head_w, G + d.head_b, e->scratch, st));
     else
         ORN_TRY(orn_launch_head_bwd(e->L[nl - 1].a, P + d.head_w, e->img, e->dimg, 1, e->Cn_last, HWo, d.sigmoid, e->L[nl - 1].da,
                                     G + d.head_w, G + d.head_b, e->scratch, st));
@@ -347,13 +350,13 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         float *dx = (i == 0) ? e->dh2 : e->L[i - 1].da;
         // dWf / dbf land directly in the 3x3 branch's gradient slots (dW3x3 = dWf, db3x3 = dbf)
         if (i >= ff) {
-            ORN_TRY(orn_launch_wgrad_bf16(b.xpad, b.dypad, l.H, l.W, l.C, l.O, l.s, 1.0f, e->scratch, G + l.w3x3, G + l.b3x3, st));
+            ORN_TRY(e->ops->wgrad(b.xpad, b.dypad, l.H, l.W, l.C, l.O, l.s, 1.0f / e->gs, e->scratch, G + l.w3x3, G + l.b3x3, st));
             if (i > ff) {
-                ORN_TRY(orn_launch_conv_bf16_dgrad(b.dypad, b.wd, l.H, l.W, l.O, l.C, e->L[i - 1].zb, e->L[i - 1].dypad,
-                                                   d.layer[i - 1].s, nullptr, st));
+                ORN_TRY(e->ops->conv_dgrad(b.dypad, b.wd, l.H, l.W, l.O, l.C, e->L[i - 1].zb, e->L[i - 1].dypad, d.layer[i - 1].s,
+                                           nullptr, st));
             } else {
-                ORN_TRY(orn_launch_conv_bf16_dgrad(b.dypad, b.wd, l.H, l.W, l.O, l.C, nullptr, nullptr, 1, e->dxn, st));
-                ORN_TRY(orn_launch_nhwc_to_nchw_f32(e->dxn, l.C, l.H, l.W, orn_dgrad_f32_slabs(l.H, l.W, l.O), dx, st));
+                ORN_TRY(e->ops->conv_dgrad(b.dypad, b.wd, l.H, l.W, l.O, l.C, nullptr, nullptr, 1, e->dxn, st));
+                ORN_TRY(e->ops->to_nchw_f32(e->dxn, l.C, l.H, l.W, e->ops->dgrad_f32_slabs(l.H, l.W, l.O), 1.0f / e->gs, dx, st));
             }
         } else
         ORN_TRY(orn_launch_conv_bwd_f32(x, b.wf, b.z, b.da, 1, l.C, l.O, l.H, l.W, l.s, dx, G + l.w3x3, G + l.b3x3, e->scratch, st));
@@ -416,4 +419,13 @@ extern "C" int orn_engine_train_steps_graph(orn_engine *e, const float *frames, 
         if (rc != hipSuccess) { orn_set_error("graph: Launch failed: %s", hipGetErrorString(rc)); return (int)rc; }
     }
     return 0;
+}
+
+// The forward conv kernel of the IEEE-half build on raw channels-last buffers (bench.py's roofline leg; the bf16
+// twin orn_conv_nhwc_bf16_fwd lives next to the kernels).
+extern "C" int orn_conv_nhwc_f16_fwd(const void *xpad, const void *wb, const float *bias_p, int H, int W, int C, int O,
+                                     int s, void *z, void *apad, void *stream)
+{
+    ORN_REQUIRE(xpad && wb && z, "conv_nhwc_f16_fwd: null pointer");
+    return orn_half_ops_f16()->conv_fwd(xpad, wb, bias_p, H, W, C, O, s, z, apad, (hipStream_t)stream);
 }

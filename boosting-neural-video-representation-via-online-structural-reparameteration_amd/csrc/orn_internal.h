@@ -62,25 +62,25 @@ int orn_launch_loss(const float *pred, const float *target, const int *frame_idx
                     int H, int W, int loss_type, float loss_scale, float *stats, float *dpred, float *ws,
                     hipStream_t st);
 
-// orn_conv_bf16.hip (bf16 MFMA fast path; channels-last bf16 buffers, see file header)
-typedef __bf16 h16;
-int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p, int H, int W, int Cin, int O, int s,
-                             h16 *z, h16 *apad, hipStream_t st);
-int orn_launch_conv_bf16_dgrad(const h16 *dypad, const h16 *wd, int H, int W, int O, int C, const h16 *zprev,
-                               h16 *dyprev, int sp, float *dx_f32, hipStream_t st);
-size_t orn_wgrad_bf16_ws_floats(int H, int W, int O);
-int orn_launch_wgrad_bf16(const h16 *xpad, const h16 *dypad, int H, int W, int C, int O, int s, float gscale,
-                          float *slabs, float *dwf, float *dbf, hipStream_t st);
-int orn_launch_prep_weights_bf16(const float *wf, const float *bf, int O, int C, int s, h16 *wb, h16 *wd, float *bias_p,
-                                 hipStream_t st);
-struct OrnPrepLayer { const float *wf, *bf; int O, C, s; h16 *wb, *wd; float *biasp; };
-int orn_launch_prep_weights_bf16_all(int n, const OrnPrepLayer *L, hipStream_t st);
-int orn_launch_nchw_to_nhwc_pad_bf16(const float *src, int C, int H, int W, h16 *dst, hipStream_t st);
-int orn_launch_nhwc_to_nchw_f32(const float *src, int C, int H, int W, int nslab, float *dst, hipStream_t st);
-int orn_dgrad_f32_slabs(int H, int W, int O);
-size_t orn_dbias_bf16_ws_floats(int H, int O);
-int orn_launch_dbias_bf16(const h16 *dypad, int H, int W, int O, int s, float gscale, float *partial, float *dbf, hipStream_t st);
-int orn_launch_head_fwd_bf16(const h16 *z, const float *w, const float *b, int C, size_t HW, int sigmoid, float *out, hipStream_t st);
-size_t orn_head_bwd_bf16_ws_floats(int C);
-int orn_launch_head_bwd_bf16(const h16 *z, const float *w, const float *out, const float *dout, int C, int H, int W, int sigmoid,
-                             int sp, float gscale, h16 *dypad, float *dw, float *db, float *ws, hipStream_t st);
+// orn_conv_bf16.hip: the 16-bit MFMA fast path (channels-last buffers, see the file header).  The file is built
+// twice (bf16 and, with -DORN_FP16, IEEE half); the engine reaches either build through this type-erased table.
+struct OrnPrepLayer { const float *wf, *bf; int O, C, s; void *wb, *wd; float *biasp; };
+struct OrnHalfOps {
+    int (*conv_fwd)(const void *xpad, const void *wb, const float *bias_p, int H, int W, int Cin, int O, int s, void *z, void *apad,
+                    hipStream_t st);
+    int (*conv_dgrad)(const void *dypad, const void *wd, int H, int W, int O, int C, const void *zprev, void *dyprev, int sp,
+                      float *dx_f32, hipStream_t st);
+    size_t (*wgrad_ws_floats)(int H, int W, int O);
+    int (*wgrad)(const void *xpad, const void *dypad, int H, int W, int C, int O, int s, float gscale, float *slabs, float *dwf,
+                 float *dbf, hipStream_t st);
+    int (*prep_all)(int n, const OrnPrepLayer *L, hipStream_t st);
+    int (*to_nhwc)(const float *src, int C, int H, int W, void *dst, hipStream_t st);
+    int (*to_nchw_f32)(const float *src, int C, int H, int W, int nslab, float scale, float *dst, hipStream_t st);
+    int (*dgrad_f32_slabs)(int H, int W, int O);
+    int (*head_fwd)(const void *z, const float *w, const float *b, int C, size_t HW, int sigmoid, float *out, hipStream_t st);
+    size_t (*head_bwd_ws_floats)(int C);
+    int (*head_bwd)(const void *z, const float *w, const float *out, const float *dout, int C, int H, int W, int sigmoid, int sp,
+                    float gs_up, void *dypad, float *dw, float *db, float *ws, hipStream_t st);
+};
+const OrnHalfOps *orn_half_ops_bf16();
+const OrnHalfOps *orn_half_ops_f16();

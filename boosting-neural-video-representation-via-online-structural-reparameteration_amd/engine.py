@@ -106,7 +106,7 @@ class TrainEngine:
                 view.copy_(p.detach().to(dev))
                 p.data = view                                   # parameters now live in the arena
                 p.grad = self.grads[off:off + n].view(p.shape)  # and their grads in the grad arena
-        self.precision = {'fp32': 0, 'bf16': 1}[precision]
+        self.precision = {'fp32': 0, 'bf16': 1, 'fp16': 2}[precision]
         self.desc = build_desc(model, self.layout, self.n_params, loss_type, beta, 0.999, 1e-8, self.precision)
         nbytes = lib().orn_engine_ws_bytes(byref(self.desc))
         if nbytes == 0:

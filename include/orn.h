@@ -97,6 +97,9 @@ int orn_conv3x3_ps_silu_bwd_bf16(const float *x, const float *wf, const float *z
  * apad [H*s+2][W*s+2][Cn] or NULL.  This is the dominant kernel bench.py prices against the MFMA roofline. */
 int orn_conv_nhwc_bf16_fwd(const void *xpad, const void *wb, const float *bias_p, int H, int W, int C, int O,
                            int s, void *z, void *apad, void *stream);
+/* the same kernel built for IEEE half (precision 2 of the engine): buffers hold fp16 */
+int orn_conv_nhwc_f16_fwd(const void *xpad, const void *wb, const float *bias_p, int H, int W, int C, int O,
+                          int s, void *z, void *apad, void *stream);
 
 /* Same for the two backward kernels (dgrad fused with SiLU' + un-shuffle into the previous layer's dypad;
  * wgrad + dbias into PyTorch-layout dwf [O][96][3][3], dbf [O]) and a timing-only ablation switch for
@@ -153,7 +156,7 @@ typedef struct orn_engine_desc {
     int32_t embed_len, stem_dim, fc_h, fc_w, fc_dim;
     int32_t sigmoid;                /* head activation (model.py:622) */
     int32_t loss_type;              /* ORN_LOSS_* */
-    int32_t precision;              /* 0: fp32 everywhere; 1: bf16 activations / bf16 MFMA convs */
+    int32_t precision;              /* 0: fp32 everywhere; 1: bf16, 2: IEEE fp16 activations + 16-bit MFMA convs (fp32 accumulate) */
     double beta1, beta2, eps;
     int64_t stem_w0, stem_b0, stem_w1, stem_b1, head_w, head_b;
     int64_t n_params;               /* arena length in floats */
