@@ -367,7 +367,7 @@ static int launch_conv_cfg(const ConvBP &p, int n_tiles_total, hipStream_t st)
     dim3 grid(ptiles, n_tiles_total / p.n_tiles_per_wg);
     if (p.qsplit) grid.y = p.Cin / CB_CK;
     q.n_full = ptiles;
-    if (p.n_tiles_per_wg > 1 && p.n_tiles_per_wg == n_tiles_total) {
+    if (p.n_tiles_per_wg > 1 && p.n_tiles_per_wg == n_tiles_total && ptiles > 256) {
         // 256 CUs, one work-group each: whole rounds keep full tiles, the last partial round is cut up
         q.n_full = ptiles / 256 * 256;
         grid = dim3(q.n_full + (ptiles - q.n_full) * p.n_tiles_per_wg, 1);
@@ -390,8 +390,12 @@ int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p
     p.tiles_w = orn_cdiv(W, CB_TW); p.tiles_h = orn_cdiv(H, CB_TH);
     p.z = z; p.apad = apad; p.s = s; p.Cn = O / (s * s);
     const int nt_total = O / 128;
-    // few pixel tiles: spread the N tiles over work-groups to fill the chip
-    p.n_tiles_per_wg = (p.tiles_w * p.tiles_h >= 512) ? nt_total : 1;
+    // One work-group per CU (LDS): keep a pixel tile's N tiles together (patch staged once) unless cutting them
+    // apart fills the chip better.  Cost model in units of one N tile: rounds x (work + ~0.3 for the patch).
+    const int ptiles = p.tiles_w * p.tiles_h;
+    const float cost_whole = (float)orn_cdiv(ptiles, 256) * nt_total;
+    const float cost_split = (float)orn_cdiv(ptiles * nt_total, 256) * 1.3f;
+    p.n_tiles_per_wg = (ptiles >= 512 || cost_whole <= cost_split) ? nt_total : 1;
     return launch_conv_cfg<4, 2, 2, 2, EPI_B_FWD>(p, nt_total, st);
 }
 
