@@ -205,7 +205,7 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
             m.dT = e->L[i].dT; m.dw1p = e->L[i].dw1p;
             m.dw2 = grads ? grads + l.w2 : nullptr; m.dw3 = grads ? grads + l.w3 : nullptr;
         }
-        const int rc = orn_merge_groups_build(e->merge_tables, d->n_layers, ml);
+        const int rc = orn_merge_groups_build(e->merge_tables, d->n_layers, ml, d->precision != 0);
         if (rc != 0) { delete e; return rc; }
         for (int k = 0; k < 4; ++k) e->merge_tiles[k] = orn_merge_group_tiles(k, d->n_layers, ml);
     }

@@ -33,7 +33,7 @@ struct OrnMergeLayer {
     float *dT, *dw1p, *dw2, *dw3;                     // backward scratch / outputs
 };
 size_t orn_merge_group_bytes();
-int orn_merge_groups_build(void *dev_tables, int n_layers, const OrnMergeLayer *L);
+int orn_merge_groups_build(void *dev_tables, int n_layers, const OrnMergeLayer *L, int bwd_h16);
 int orn_merge_group_tiles(int which, int n_layers, const OrnMergeLayer *L);
 int orn_launch_merge_group(const void *dev_tables, int which, int tiles, hipStream_t st);
 int orn_launch_merge_bias(const float *b3x3, const float *b1x3, const float *b3x1, int O, float *bf, hipStream_t st);

@@ -19,6 +19,9 @@ struct GemmP {
     int epi;
     const float *w3x3, *w1x3, *w3x1;
     int Cch;
+    // 16-bit MFMA variant (merge backward in the 16-bit engine modes): operands are multiplied by sa / sb when they
+    // are rounded to IEEE half (gradient operands ~1e-6 would be subnormal), the result by so = 1/(sa*sb)
+    float sa, sb, so;
 };
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -113,6 +116,84 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, int bx, int by, int bz
     }
 }
 
+// Same tiling on v_mfma_f32_32x32x16_f16 (fp32 accumulate): operands are rounded to IEEE half while they are
+// staged into LDS ([row][k], k contiguous, 144-byte rows: conflict-free ds_read_b128).  Used for the merge BACKWARD
+// in the 16-bit engine modes only -- the forward merge stays exact fp32.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+#define HK 64
+#define HROW (HK * 2 + 16)
+
+__device__ __forceinline__ void gemm_body_h16(const GemmP &p, int bx, int by, int bz)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char Ah[GT * HROW];
+    __shared__ __attribute__((aligned(16))) unsigned char Bh[GT * HROW];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = by * GT, n0 = bx * GT;
+    const float *A = p.A + (long)bz * p.ba;
+    const float *B = p.B + (long)bz * p.bb;
+    float *C = p.C + (long)bz * p.bc;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int NE = GT * HK / 256;
+    float ra[NE], rb[NE];
+    long aoff[NE], boff[NE];
+    int alds[NE], blds[NE], akk[NE], bkk[NE];
+    bool aok[NE], bok[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        int kk, m;
+        if (p.a_kfast) { kk = t & 63; m = (t >> 6) + 4 * i; }
+        else           { m = t & 63;  kk = (t >> 6) + 4 * i; }
+        aoff[i] = (long)(m0 + m) * p.sam + (long)kk * p.sak;
+        alds[i] = m * HROW + kk * 2;
+        akk[i] = kk;
+        aok[i] = (m0 + m) < p.M;
+        int kb, n;
+        if (p.b_nfast) { n = t & 63;  kb = (t >> 6) + 4 * i; }
+        else           { kb = t & 63; n = (t >> 6) + 4 * i; }
+        boff[i] = (long)kb * p.sbk + (long)(n0 + n) * p.sbn;
+        blds[i] = n * HROW + kb * 2;
+        bkk[i] = kb;
+        bok[i] = (n0 + n) < p.N;
+    }
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            ra[i] = (aok[i] && k0 + akk[i] < p.K) ? A[aoff[i] + (long)k0 * p.sak] : 0.f;
+            rb[i] = (bok[i] && k0 + bkk[i] < p.K) ? B[boff[i] + (long)k0 * p.sbk] : 0.f;
+        }
+    };
+    gload(0);
+    for (int k0 = 0; k0 < p.K; k0 += HK) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            *reinterpret_cast<_Float16 *>(Ah + alds[i]) = (_Float16)(ra[i] * p.sa);
+            *reinterpret_cast<_Float16 *>(Bh + blds[i]) = (_Float16)(rb[i] * p.sb);
+        }
+        __syncthreads();
+        if (k0 + HK < p.K) gload(k0 + HK);
+        const unsigned char *ap = Ah + (wm * 32 + l31) * HROW + hh * 16;
+        const unsigned char *bp = Bh + (wn * 32 + l31) * HROW + hh * 16;
+#pragma unroll
+        for (int ks = 0; ks < HK / 16; ++ks) {
+            const f16x8 a = *reinterpret_cast<const f16x8 *>(ap + ks * 32);
+            const f16x8 b = *reinterpret_cast<const f16x8 *>(bp + ks * 32);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+        }
+    }
+    const int gn = n0 + wn * 32 + l31;
+    if (gn >= p.N) return;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int gm = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+        if (gm < p.M) C[(long)gm * p.scm + (long)gn * p.scn] = acc[reg] * p.so;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_gemm_f32(GemmP p) { gemm_body(p, blockIdx.x, blockIdx.y, blockIdx.z); }
 
 // Grouped form: several independent problems in one launch (the engine merges all layers at once so
@@ -120,6 +201,7 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmP p) { gemm_body(p, blockI
 #define GEMM_MAXP 16
 struct GemmGroup {
     int n;
+    int h16;                    // 1: problems run on the 16-bit MFMA variant
     int tile_start[GEMM_MAXP + 1];
     GemmP prob[GEMM_MAXP];
 };
@@ -133,7 +215,8 @@ __global__ void __launch_bounds__(256) k_gemm_f32_grouped(const GemmGroup *__res
     const int local = bid - g->tile_start[pi];
     const int tn = (p.N + GT - 1) / GT, tm = (p.M + GT - 1) / GT;
     const int bz = local / (tn * tm), rem = local - bz * tn * tm;
-    gemm_body(p, rem % tn, rem / tn, bz);
+    if (g->h16) gemm_body_h16(p, rem % tn, rem / tn, bz);
+    else gemm_body(p, rem % tn, rem / tn, bz);
 }
 
 static void finish_gemm(GemmP &p)
@@ -329,7 +412,7 @@ static void group_add(GemmGroup &g, GemmP p, int batch)
 size_t orn_merge_group_bytes() { return orn_align(4 * sizeof(GemmGroup)); }
 
 // Builds the four device-resident problem tables (host side, at engine creation; synchronous copy).
-int orn_merge_groups_build(void *dev_tables, int n_layers, const OrnMergeLayer *L)
+int orn_merge_groups_build(void *dev_tables, int n_layers, const OrnMergeLayer *L, int bwd_h16)
 {
     ORN_REQUIRE(2 * n_layers <= GEMM_MAXP, "merge groups: too many layers");
     GemmGroup *h = new GemmGroup[4]();
@@ -337,11 +420,15 @@ int orn_merge_groups_build(void *dev_tables, int n_layers, const OrnMergeLayer *
         const OrnMergeLayer &l = L[i];
         group_add(h[0], prob_T(l.w1, l.w2, l.C, l.O, l.T), 9);
         group_add(h[1], prob_S(l.w3x3, l.w3x1, l.w1x3, l.w3, l.T, l.C, l.O, l.wf), 1);
-        group_add(h[2], prob_dW3(l.g, l.T, l.C, l.O, l.dw3), 1);
-        group_add(h[2], prob_dT(l.g, l.w3, l.C, l.O, l.dT), 1);
-        group_add(h[3], prob_dW2(l.dT, l.w1, l.C, l.O, l.dw2), 9);
-        group_add(h[3], prob_dW1p(l.w2, l.dT, l.C, l.O, l.dw1p), 9);
+        // gradient operands (dWf, dT ~ 1e-6) are scaled by 2^14 when rounded to half; weights are not
+        const float GS = 16384.0f;
+        GemmP q;
+        q = prob_dW3(l.g, l.T, l.C, l.O, l.dw3);   q.sa = GS;   q.sb = 1.0f; q.so = 1.0f / GS; group_add(h[2], q, 1);
+        q = prob_dT(l.g, l.w3, l.C, l.O, l.dT);    q.sa = 1.0f; q.sb = GS;   q.so = 1.0f / GS; group_add(h[2], q, 1);
+        q = prob_dW2(l.dT, l.w1, l.C, l.O, l.dw2); q.sa = GS;   q.sb = 1.0f; q.so = 1.0f / GS; group_add(h[3], q, 9);
+        q = prob_dW1p(l.w2, l.dT, l.C, l.O, l.dw1p); q.sa = 1.0f; q.sb = GS; q.so = 1.0f / GS; group_add(h[3], q, 9);
     }
+    h[2].h16 = h[3].h16 = bwd_h16 ? 1 : 0;
     hipError_t e = hipMemcpy(dev_tables, h, 4 * sizeof(GemmGroup), hipMemcpyHostToDevice);
     delete[] h;
     if (e != hipSuccess) { orn_set_error("merge groups: hipMemcpy failed: %s", hipGetErrorString(e)); return (int)e; }
