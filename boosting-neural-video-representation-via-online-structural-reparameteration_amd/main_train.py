@@ -101,21 +101,12 @@ def load_frames(args, hw, device):
 
 def save_checkpoint(args, model, eng, epoch, best_psnr, name='model_latest.pth'):
     """main_train.py:293-301,327 layout; ERB also writes the deploy copy (main_train.py:325-351)."""
-    os.makedirs(args.outf, exist_ok=True)
-    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    ck = {'epoch': epoch + 1, 'state_dict': sd, 'train_best_psnr': best_psnr, 'train_best_msssim': torch.tensor(0),
-          'val_best_psnr': best_psnr, 'val_best_msssim': torch.tensor(0),
-          'optimizer': {'adam_m': eng.adam_m.cpu(), 'adam_v': eng.adam_v.cpu(), 'step': eng.global_step, 'layout': eng.layout}}
-    torch.save(ck, os.path.join(args.outf, name))
+    from . import checkpoint
+    opt = {'adam_m': eng.adam_m.cpu(), 'adam_v': eng.adam_v.cpu(), 'step': eng.global_step, 'layout': eng.layout}
+    checkpoint.save(os.path.join(args.outf, name), model, epoch + 1, opt, best_psnr, best_psnr)
     if args.branch_type == 'ERB':
-        dsd = {k: v for k, v in sd.items() if not k.startswith('layers.')}
-        for i, blk in enumerate(model.layers):
-            with torch.no_grad():
-                wf, bf = blk.get_equivalent_kernel_bias()
-            dsd[f'layers.{i}.rbr_reparam.weight'] = wf.cpu()
-            dsd[f'layers.{i}.rbr_reparam.bias'] = bf.cpu()
-        ck_d = dict(ck, state_dict=dsd)
-        torch.save(ck_d, os.path.join(args.outf, name.replace('.pth', '_deploy.pth')))
+        checkpoint.save(os.path.join(args.outf, name.replace('.pth', '_deploy.pth')), model, epoch + 1, opt, best_psnr, best_psnr,
+                        deploy=True)
 
 
 def evaluate(model, eng, args):

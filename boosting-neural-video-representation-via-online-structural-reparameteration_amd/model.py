@@ -75,6 +75,19 @@ class NeRVBlock(nn.Module):
                 self.__delattr__(name)
         self.deploy = True
 
+    def switch_to_deploy_structure(self):
+        """Module surgery of switch_to_deploy without computing the merge (the deploy checkpoint supplies the
+        merged kernel): creates rbr_reparam, drops the training branches.  No GPU needed."""
+        if getattr(self, 'deploy', False):
+            return
+        if not hasattr(self, 'rbr_reparam'):
+            self.rbr_reparam = nn.Conv2d(self.ngf, self.out_channels, (3, 3), 1, 1, bias=True)
+        for name in ['rbr_3x3_branch', 'rbr_3x1_branch', 'rbr_1x3_branch', 'rbr_1x1_3x3_1x1_branch_1x1_1',
+                     'rbr_1x1_3x3_1x1_branch_3x3', 'rbr_1x1_3x3_1x1_branch_1x1_2', 'branch']:
+            if hasattr(self, name):
+                self.__delattr__(name)
+        self.deploy = True
+
     # model.py:518-567
     def forward(self, x):
         if self.deploy:

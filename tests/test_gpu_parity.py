@@ -371,3 +371,37 @@ def test_engine_matches_oracle_training(orn, bt, graph):
         img_e = eng.decode(embeds[2])
         img_m = gen(embeds[2:3].cuda())[0]
     assert torch.allclose(img_e, img_m, rtol=0, atol=1e-6)
+
+
+def test_deploy_checkpoint_round_trip(orn, golden, tmp_path):
+    """N1: a reference *_deploy.pth decodes frame-for-frame; our deploy export of a trained ERB model
+    equals the reference's switch_to_deploy result and decodes identically through the engine's decode path."""
+    from orn_amd import checkpoint
+    g = golden('generator')
+
+    def mk():
+        torch.manual_seed(1)
+        return orn.model.Generator(embed_length=80, stem_dim_num='32_1', fc_hw_dim='3_4_8', expansion=1, num_blocks=1,
+                                   norm='none', act='swish', bias=True, reduction=2, conv_type='conv', stride_list=[2, 2],
+                                   sin_res=True, lower_width=8, sigmoid=False, deploy=False, branch_type='ERB')
+    embed = cu(g['tiny_ERB/embed'])
+    # (1) reference deploy file -> mirror -> same image as the reference produced
+    dsd = {str(k): T(g[f'tiny_ERB/deploy_sd/{k}']) for k in g['tiny_ERB/deploy_keys']}
+    path = tmp_path / 'model_latest_deploy.pth'
+    torch.save({'epoch': 1, 'state_dict': dsd}, path)
+    gen = mk()
+    assert checkpoint.load_into(gen, checkpoint.load_state_dict_file(str(path))) == 'deploy'
+    gen = gen.cuda()
+    with torch.no_grad():
+        img = gen(embed)[0]
+    np.testing.assert_allclose(img.cpu().numpy(), g['tiny_ERB/deploy_img'], rtol=1e-5, atol=2e-6)
+    # (2) our export of the train-time model == the reference's deploy state dict (merge within 1e-7)
+    gen_t = mk().cuda()
+    exp = checkpoint.deploy_state_dict(gen_t)
+    assert list(exp.keys()) == [str(k) for k in g['tiny_ERB/deploy_keys']]
+    for k in exp:
+        assert np.max(np.abs(exp[k].numpy() - g[f'tiny_ERB/deploy_sd/{k}'])) <= 1e-7, k
+    # (3) the engine's decode path on the deploy model == eager forward
+    eng = orn.engine.TrainEngine(gen, loss_type='L2', beta=0.5)
+    with torch.no_grad():
+        assert torch.allclose(eng.decode(embed[0]), img, rtol=0, atol=1e-6)

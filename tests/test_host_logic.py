@@ -122,3 +122,84 @@ def test_lr_schedule_matches_reference(orn, golden):
     assert utils.adjust_lr(opt, 30, 0, 132, A) == pytest.approx(2.75e-4) and opt.param_groups[0]['lr'] == pytest.approx(2.75e-4)
     pe = utils.PositionalEncoding('1.25_40')
     assert pe.embed_length == 80 and pe.lbase == 1.25 and pe.levels == 40
+
+
+def test_checkpoint_interchange_layouts(orn, golden, tmp_path):
+    """Reference-format checkpoints (train ERB and deploy key layouts) load into the mirror, safely
+    (weights_only), and the deploy structure switch needs no GPU."""
+    from orn_amd import checkpoint, model
+    g = golden('generator')
+
+    def mk(bt='ERB'):
+        torch.manual_seed(1)
+        return model.Generator(embed_length=80, stem_dim_num='32_1', fc_hw_dim='3_4_8', expansion=1, num_blocks=1, norm='none',
+                               act='swish', bias=True, reduction=2, conv_type='conv', stride_list=[2, 2], sin_res=True,
+                               lower_width=8, sigmoid=False, deploy=False, branch_type=bt)
+    # a reference train checkpoint (state dict captured from the reference) with thop's stray buffers
+    sd = {str(k): torch.from_numpy(g[f'tiny_ERB/sd/{k}']) for k in g['tiny_ERB/keys']}
+    sd['layers.0.total_ops'] = torch.zeros(1)
+    path = tmp_path / 'model_latest.pth'
+    torch.save({'epoch': 3, 'state_dict': sd, 'train_best_psnr': torch.tensor(1.0), 'optimizer': {}}, path)
+    loaded = checkpoint.load_state_dict_file(str(path))
+    assert 'layers.0.total_ops' not in loaded and checkpoint.state_dict_kind(loaded) == 'ERB'
+    gen = mk()
+    assert checkpoint.load_into(gen, loaded) == 'ERB'
+    for k in g['tiny_ERB/keys']:
+        assert np.array_equal(gen.state_dict()[str(k)].numpy(), g[f'tiny_ERB/sd/{k}'])
+    # a reference deploy checkpoint
+    dsd = {str(k): torch.from_numpy(g[f'tiny_ERB/deploy_sd/{k}']) for k in g['tiny_ERB/deploy_keys']}
+    dpath = tmp_path / 'model_latest_deploy.pth'
+    torch.save({'epoch': 3, 'state_dict': dsd}, dpath)
+    gen2 = mk()
+    assert checkpoint.load_into(gen2, checkpoint.load_state_dict_file(str(dpath))) == 'deploy'
+    assert list(gen2.state_dict().keys()) == [str(k) for k in g['tiny_ERB/deploy_keys']]
+    assert all(b.deploy for b in gen2.layers)
+    assert np.array_equal(gen2.layers[1].rbr_reparam.weight.detach().numpy(), g['tiny_ERB/deploy_sd/layers.1.rbr_reparam.weight'])
+    # vanilla layout is recognised too; garbage is rejected
+    assert checkpoint.state_dict_kind(mk('NeRV_vanilla').state_dict()) == 'NeRV_vanilla'
+    with pytest.raises(ValueError):
+        checkpoint.state_dict_kind({'foo': torch.zeros(1)})
+    # our own save() writes the reference's dict keys
+    ck = checkpoint.save(str(tmp_path / 'x' / 'model_latest.pth'), mk('NeRV_vanilla'), epoch=7)
+    assert set(ck.keys()) == {'epoch', 'state_dict', 'train_best_psnr', 'train_best_msssim', 'val_best_psnr', 'val_best_msssim', 'optimizer'}
+
+
+def test_quantize_per_tensor_matches_reference(orn, golden):
+    """utils.py:11-67 incl. the mask->ones and zero-handling quirks, from the reference's own outputs."""
+    from orn_amd import eval_utils
+    g = golden('utils')
+    cases = sorted({k.split('/')[1] + '/' + k.split('/')[2] for k in g.files if k.startswith('quant/')})
+    assert len(cases) >= 10
+    for c in cases:
+        axis = int(c.split('axis')[1])
+        if f'quant/{c}/raises' in g.files:
+            with pytest.raises(Exception):
+                eval_utils.quantize_per_tensor(torch.zeros(17), 8, axis)
+            continue
+        t = torch.from_numpy(g[f'quant/{c}/in'])
+        q, n = eval_utils.quantize_per_tensor(t.clone(), 8, axis)
+        assert np.array_equal(q.numpy(), g[f'quant/{c}/quant']), c
+        assert np.array_equal(n.numpy(), g[f'quant/{c}/new']), c
+    # quirk Q3: a 0/1 mask row becomes all ones
+    qm, nm = eval_utils.quantize_per_tensor(torch.tensor([[1., 0., 1.], [0., 0., 0.]]), 8, 0)
+    assert torch.equal(nm[0], torch.ones(3))
+
+
+def test_prune_and_huffman(orn):
+    from orn_amd import eval_utils
+    import torch.nn.utils.prune as prune
+    torch.manual_seed(0)
+    a, b = torch.nn.Linear(13, 7), torch.nn.Conv2d(3, 5, 3)
+    masks = eval_utils.global_l1_prune_masks({'a': a.weight, 'b': b.weight}, 0.4)
+    prune.global_unstructured([(a, 'weight'), (b, 'weight')], pruning_method=prune.L1Unstructured, amount=0.4)
+    assert torch.equal(masks['a'], a.weight_mask) and torch.equal(masks['b'], b.weight_mask)
+    # Huffman: known answer (frequencies 5,9,12,13,16,45 -> 224 bits), single-symbol stream, and the entropy bound
+    syms = [0] * 5 + [1] * 9 + [2] * 12 + [3] * 13 + [4] * 16 + [5] * 45
+    assert eval_utils.huffman_total_bits(syms) == 224
+    assert eval_utils.huffman_total_bits([7] * 10) == 10
+    import math
+    n = len(syms)
+    ent = -sum(c / n * math.log2(c / n) for c in (5, 9, 12, 13, 16, 45)) * n
+    assert ent <= 224 < ent + n
+    sd, bits, count = eval_utils.quantized_model_bits({'w': torch.randn(6, 10), 'b': torch.randn(6)}, 8, 0)
+    assert count == 66 and 0 < bits <= 66 * 9 and sd['w'].shape == (6, 10)
