@@ -1,0 +1,34 @@
+"""End-to-end CLI mirrors (main_train.py / main_eval.py flags of the reference README) on the GPU: short ERB run on a
+synthetic clip, checkpoints in the reference's layout, then prune + quantise + evaluate (BASELINE config 5 flow)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FLAGS = ('-e 4 --lower_width 96 --num_blocks 1 --dataset bunny --frame_gap 1 --embed 1.25_40 --stem_dim_num 512_1 '
+         '--reduction 2 --fc_hw_dim 9_16_26 --expansion 1 --single_res --loss Fusion6 --warmup 0.2 --lr_type cosine '
+         '--strides 5 2 2 2 2 --conv_type conv -b 1 --lr 0.0005 --norm none --act swish --outf bunny_erb_t --branch_type ERB '
+         '--synthetic 12 --eval_freq 2').split()
+
+
+def test_train_then_eval_cli(tmp_path, monkeypatch):
+    import orn_amd
+    from orn_amd import checkpoint, main_eval, main_train
+    monkeypatch.chdir(tmp_path)
+    best = main_train.train(main_train.parse_args(FLAGS))
+    assert 10.0 < best < 60.0
+    outf = tmp_path / 'result' / 'bunny_erb_t'
+    for f in ('model_latest.pth', 'model_latest_deploy.pth', 'rank0.txt'):
+        assert (outf / f).exists(), f
+    ck = torch.load(outf / 'model_latest.pth', map_location='cpu', weights_only=False)
+    assert set(ck) >= {'epoch', 'state_dict', 'train_best_psnr', 'val_best_psnr', 'optimizer'} and ck['epoch'] == 4
+    sd = checkpoint.load_state_dict_file(str(outf / 'model_latest_deploy.pth'))
+    assert checkpoint.state_dict_kind(sd) == 'deploy' and len(sd) == 4 + 5 * 2 + 2
+    psnr_plain = main_eval.main(FLAGS)
+    psnr_pq = main_eval.main(FLAGS + ['--prune_ratio', '0.4', '--quant_bit', '8'])
+    assert abs(psnr_plain - best) < 3.0          # decode of the deploy file reproduces the training-time quality
+    assert psnr_pq <= psnr_plain + 0.5 and psnr_pq > 5.0
+    with pytest.raises(NotImplementedError):
+        main_eval.main(FLAGS + ['--finetune'])
