@@ -206,6 +206,10 @@ def main():
 
     if rank == 0:
         fl, avg_dt, per_layer = conv_roofline(eng, args.precision)
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'conv_fwd_traffic.json')
+        if args.precision != 'fp32' and os.path.exists(tpath):       # PMC pass collected separately (see the file's "method")
+            traffic = json.load(open(tpath))['traffic_per_launch']
         peak = 157.3 if args.precision == 'fp32' else 2500.0      # fp32 MFMA / dense 16-bit MFMA (bf16 and f16 share the rate)
         achieved = fl / avg_dt / 1e12
         out = {
@@ -219,7 +223,7 @@ def main():
                        'train_psnr_mean_timed_steps': psnr_last, 'finite': ok,
                        'whole_step_tflops': world * args.steps / dt * FLOP_STEP / 1e12},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'traffic': None,
+                         'traffic': traffic,
                          'kernel': ('k_conv3x3_f32<EPI_PS_SILU> (5 launches/step, L0..L4)' if args.precision == 'fp32'
                                     else f'orn_{"bf16" if args.precision == "bf16" else "f16"}::k_conv_nhwc_bf16<4,2,2,2,EPI_B_FWD> (3 launches/step, L2..L4)'),
                          'flops_per_launch': fl, 'avg_launch_ms': avg_dt * 1e3, 'per_layer': per_layer},
