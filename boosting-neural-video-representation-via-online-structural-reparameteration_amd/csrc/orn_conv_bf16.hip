@@ -732,7 +732,7 @@ int orn_launch_prep_weights_bf16(const float *wf, const float *bf, int O, int C,
 
 // fp32 NCHW [C][H][W] -> bf16 padded NHWC [H+2][W+2][C] interior (border stays zero).
 // 64-pixel x C tile through LDS: coalesced along pixels on the read, along channels on the write.
-#define TR_PX 64
+#define TR_PX 16
 #define TR_MAXC 128
 __global__ void __launch_bounds__(256) k_nchw_to_nhwc_pad_bf16(const float *__restrict__ src, int C, int H, int W, h16 *__restrict__ dst)
 {

@@ -100,16 +100,17 @@ __global__ void __launch_bounds__(256) k_ssim_stats(LossP q)
     __syncthreads();
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     float ssum = 0.f;
-    {   // vertical pass: item = (column c, 4 rows r4..r4+3); 256 items = one per thread
-        const int c = t & (SS_TW - 1), r4 = (t / SS_TW) * 4;
-        float v[5][4];
+    {   // vertical pass: item = (column c, RPT rows r4..r4+RPT-1); 256 items = one per thread
+        constexpr int RPT = SS_TH * SS_TW / 256;
+        const int c = t & (SS_TW - 1), r4 = (t / SS_TW) * RPT;
+        float v[5][RPT];
 #pragma unroll
         for (int m = 0; m < 5; ++m) {
-            float col[14];
+            float col[RPT + 10];
 #pragma unroll
-            for (int k = 0; k < 14; ++k) col[k] = Hs[m][r4 + k][c];
+            for (int k = 0; k < RPT + 10; ++k) col[k] = Hs[m][r4 + k][c];
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
+            for (int o = 0; o < RPT; ++o) {
                 float acc = 0.f;
 #pragma unroll
                 for (int k = 0; k < 11; ++k) acc = fmaf(c_gauss[k], col[o + k], acc);
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(256) k_ssim_stats(LossP q)
             }
         }
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
+        for (int o = 0; o < RPT; ++o) {
             const int gy = y0 + r4 + o, gx = x0 + c;
             if (gy >= q.Hv || gx >= q.Wv) continue;
             const float m = v[0][o], mu = v[1][o], qq = v[2][o], tt = v[3][o], rr = v[4][o];
