@@ -618,11 +618,14 @@ __global__ void k_wgrad_bf16_reduce(const float *__restrict__ slabs, const float
 
 int orn_wgrad_bf16_split(int H, int W, int O)
 {
+    // S slabs of 9*O*96 floats are written and re-read: keep >= 16 K tiles per work-group so the slab traffic
+    // stays small next to the layer's own data, up to one full wave of work-groups (2 per CU)
     const int n_ktiles = orn_cdiv(H, WB_TH) * orn_cdiv(W, WB_TW);
     const int per = 3 * (O / WB_BO);
     int S = (512 / per) / 8 * 8;
+    const int by_work = (n_ktiles / 16) / 8 * 8;
+    if (S > by_work) S = by_work;
     if (S < 8) S = 8;
-    while (S > 8 && S > n_ktiles) S -= 8;
     return S;
 }
 

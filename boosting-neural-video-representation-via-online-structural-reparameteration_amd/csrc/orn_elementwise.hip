@@ -184,7 +184,7 @@ __global__ void k_linear_bwd_x_partial(const float *__restrict__ w, const float 
     }
 }
 
-#define ORN_STEM_CHUNKS 64
+#define ORN_STEM_CHUNKS 256
 
 int orn_launch_stem_bwd(const float *embed, const int *row_idx, size_t row_stride, const float *w1, const float *pre1,
                         const float *h1, const float *pre2, const float *dh2, int B, int E, int Hd, int Nout,

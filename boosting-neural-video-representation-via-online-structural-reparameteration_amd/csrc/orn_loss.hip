@@ -233,18 +233,18 @@ __global__ void __launch_bounds__(256) k_loss_grad(LossP q)
 }
 
 // One block; fixed-order strided partial sums in double, then a fixed tree.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_loss_finalize(const float *__restrict__ part_ssim, int n_ssim, const float *__restrict__ part_l1, int n_l1,
                 double n_elem, double n_map, int loss_type, float loss_scale, float *__restrict__ stats)
 {
-    __shared__ double sd[3][256];
+    __shared__ double sd[3][1024];
     const int t = threadIdx.x;
     double a = 0.0, b = 0.0, c = 0.0;
-    for (int i = t; i < n_l1; i += 256) { a += (double)part_l1[2 * i]; b += (double)part_l1[2 * i + 1]; }
-    for (int i = t; i < n_ssim; i += 256) c += (double)part_ssim[i];
+    for (int i = t; i < n_l1; i += 1024) { a += (double)part_l1[2 * i]; b += (double)part_l1[2 * i + 1]; }
+    for (int i = t; i < n_ssim; i += 1024) c += (double)part_ssim[i];
     sd[0][t] = a; sd[1][t] = b; sd[2][t] = c;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = 512; s > 0; s >>= 1) {
         if (t < s) { sd[0][t] += sd[0][t + s]; sd[1][t] += sd[1][t + s]; sd[2][t] += sd[2][t + s]; }
         __syncthreads();
     }
@@ -339,7 +339,7 @@ int orn_launch_loss(const float *pred, const float *target, const int *frame_idx
     }
     hipLaunchKernelGGL(k_loss_grad, dim3(g.tw * g.th, g.planes), dim3(256), 0, st, q);
     ORN_LAUNCH_CHECK("loss_grad");
-    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, st, q.part_ssim, n_ssim, q.part_l1, g.planes * g.tw * g.th, n,
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, st, q.part_ssim, n_ssim, q.part_l1, g.planes * g.tw * g.th, n,
                        (double)g.nmap, loss_type, loss_scale, stats);
     ORN_LAUNCH_CHECK("loss_finalize");
     return 0;

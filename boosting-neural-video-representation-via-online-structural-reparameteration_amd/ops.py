@@ -65,7 +65,7 @@ class StemFn(torch.autograd.Function):
         db0 = torch.empty(Hd, device=dev)
         dw1 = torch.empty(Nout, Hd, device=dev)
         db1 = torch.empty(Nout, device=dev)
-        ws = torch.empty(B * Nout + 2 * B * Hd + 64 * B * Hd, device=dev)
+        ws = torch.empty(B * Nout + 2 * B * Hd + 256 * B * Hd, device=dev)
         check(lib().orn_stem_bwd(ptr(embed), ptr(w1), ptr(pre1), ptr(h1), ptr(pre2), ptr(dh2), B, E, Hd, Nout,
                                  ptr(dw0), ptr(db0), ptr(dw1), ptr(db1), ptr(ws), stream()), 'orn_stem_bwd')
         return None, dw0, db0, dw1, db1

@@ -51,7 +51,7 @@ int orn_pe_fwd(const float *pos, int B, const float *lbase_pow, int levels, floa
 int orn_stem_fwd(const float *embed, const float *w0, const float *b0, const float *w1, const float *b1,
                  int B, int E, int Hd, int Nout, float *pre1, float *h1, float *pre2, float *h2,
                  void *stream);
-/* dh2 [B,Nout] -> dw0,db0,dw1,db1 (overwritten).  ws: B*(Hd+Nout) floats. */
+/* dh2 [B,Nout] -> dw0,db0,dw1,db1 (overwritten).  ws: B*(Nout + 258*Hd) floats. */
 int orn_stem_bwd(const float *embed, const float *w1, const float *pre1, const float *h1, const float *pre2,
                  const float *dh2, int B, int E, int Hd, int Nout, float *dw0, float *db0, float *dw1,
                  float *db1, float *ws, void *stream);
