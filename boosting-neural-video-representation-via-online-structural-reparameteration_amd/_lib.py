@@ -59,6 +59,8 @@ _SIGS = {
     'orn_head_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
     'orn_loss_ws_bytes': (c_size_t, [c_int] * 4),
     'orn_loss_fwd_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, P, P, P, c_size_t, P]),
+    'orn_msssim_ws_bytes': (c_size_t, [c_int] * 4),
+    'orn_msssim': (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
     'orn_adam_step': (c_int, [P, P, P, P, c_size_t, c_double, c_double, c_double, c_double, c_int, P]),
     'orn_engine_ws_bytes': (c_size_t, [POINTER(EngineDesc)]),
     'orn_engine_create': (c_int, [POINTER(EngineDesc), P, P, P, P, P, c_size_t, POINTER(c_void_p)]),

@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
     constexpr int B_INSTR = BS_BYTES / 1024;           // wave-instructions per weight tile
     constexpr int B_PER_WAVE = (B_INSTR + NWAVES - 1) / NWAVES;
     constexpr int P_PER_WAVE = 64 / NWAVES;
-    static_assert(NWAVES == 8 && BS_BYTES % 1024 == 0, "tile geometry");
+    static_assert(64 % NWAVES == 0 && BS_BYTES % 1024 == 0, "tile geometry");
     unsigned char *patch = smem;
     unsigned char *bs0 = smem + PATCH_LDS;
 
@@ -253,7 +253,10 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
             }
             if (has_next) {
                 // tile tt+1 was issued two tiles ago: let only tile tt+2's DMA stay in flight, then rendezvous
-                if (tt + 2 < n_tiles) { if (B_PER_WAVE == 3) WAIT_VM(3); else WAIT_VM(2); }
+                if (tt + 2 < n_tiles) {
+                    if (B_PER_WAVE == 6) WAIT_VM(6); else if (B_PER_WAVE == 5) WAIT_VM(5); else if (B_PER_WAVE == 4) WAIT_VM(4);
+                    else if (B_PER_WAVE == 3) WAIT_VM(3); else WAIT_VM(2);
+                }
                 else WAIT_VM(0);
                 if (!(p.dbg & 8)) BARRIER();
                 if (!same_chunk) {                  // everyone is done with the old chunk's patch

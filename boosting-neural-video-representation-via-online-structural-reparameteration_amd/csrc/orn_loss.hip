@@ -358,3 +358,185 @@ extern "C" int orn_loss_fwd_bwd(const float *pred, const float *target, int B, i
     return orn_launch_loss(pred, target, nullptr, 0, B, Ch, H, W, loss_type, loss_scale, stats, dpred, (float *)ws,
                            (hipStream_t)stream);
 }
+
+// ================================================================================================
+// N3  msssim_fn (utils.py:201-211): pytorch_msssim.ms_ssim, 5 scales, weights (0.0448, 0.2856, 0.3001, 0.2363,
+// 0.1333), avg_pool2d(2) between scales (parity unpinned like SSIM: the package is not in the reference tree).
+// Logging metric only -- kept off the timed training path.
+// ================================================================================================
+// per-block partial sums of ssim_map and cs_map over a 16x64 tile of one plane
+__global__ void __launch_bounds__(256)
+k_ssim_cs_partial(const float *__restrict__ x, const float *__restrict__ y, int H, int W, int tiles_w, float *__restrict__ part)
+{
+    __shared__ __attribute__((aligned(16))) float Ps[SS_PH][SS_PWP];
+    __shared__ __attribute__((aligned(16))) float Ts[SS_PH][SS_PWP];
+    __shared__ float Hs[5][SS_PH][SS_TW];
+    __shared__ float sred[16];
+    const int t = threadIdx.x, plane = blockIdx.y;
+    const int tw = blockIdx.x % tiles_w, th = blockIdx.x / tiles_w;
+    const int y0 = th * SS_TH, x0 = tw * SS_TW;
+    const int Hv = H - 10, Wv = W - 10;
+    const float *pp = x + (size_t)plane * H * W, *tp = y + (size_t)plane * H * W;
+    for (int idx = t; idx < SS_PH * SS_PWP; idx += 256) {
+        const int r = idx / SS_PWP, c = idx - r * SS_PWP;
+        const int gy = y0 + r, gx = x0 + c;
+        const bool ok = c < SS_PW && gy < H && gx < W;
+        Ps[r][c] = ok ? pp[(size_t)gy * W + gx] : 0.f;
+        Ts[r][c] = ok ? tp[(size_t)gy * W + gx] : 0.f;
+    }
+    __syncthreads();
+    for (int idx = t; idx < SS_PH * SS_TW; idx += 256) {
+        const int r = idx / SS_TW, c = idx - r * SS_TW;
+        float sp = 0.f, st = 0.f, spp = 0.f, stt = 0.f, spt = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float g = c_gauss[k], a = Ps[r][c + k], b = Ts[r][c + k];
+            sp = fmaf(g, a, sp); st = fmaf(g, b, st);
+            spp = fmaf(g, a * a, spp); stt = fmaf(g, b * b, stt); spt = fmaf(g, a * b, spt);
+        }
+        Hs[0][r][c] = sp; Hs[1][r][c] = st; Hs[2][r][c] = spp; Hs[3][r][c] = stt; Hs[4][r][c] = spt;
+    }
+    __syncthreads();
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    float ss = 0.f, cs = 0.f;
+    for (int idx = t; idx < SS_TH * SS_TW; idx += 256) {
+        const int r = idx / SS_TW, c = idx - r * SS_TW;
+        if (y0 + r >= Hv || x0 + c >= Wv) continue;
+        float m = 0.f, mu = 0.f, qq = 0.f, tt = 0.f, rr = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float g = c_gauss[k];
+            m = fmaf(g, Hs[0][r + k][c], m); mu = fmaf(g, Hs[1][r + k][c], mu);
+            qq = fmaf(g, Hs[2][r + k][c], qq); tt = fmaf(g, Hs[3][r + k][c], tt); rr = fmaf(g, Hs[4][r + k][c], rr);
+        }
+        const float csm = (2.f * (rr - m * mu) + C2) / ((qq - m * m) + (tt - mu * mu) + C2);
+        cs += csm;
+        ss += ((2.f * m * mu + C1) / (m * m + mu * mu + C1)) * csm;
+    }
+    const float a = orn_block_sum(ss, sred);
+    const float b = orn_block_sum(cs, sred);
+    if (t == 0) {
+        const size_t bi = (size_t)plane * gridDim.x + blockIdx.x;
+        part[2 * bi] = a;
+        part[2 * bi + 1] = b;
+    }
+}
+
+// avg_pool2d(kernel 2, padding = size % 2, count_include_pad = True) of every plane
+__global__ void k_avgpool2(const float *__restrict__ in, int planes, int H, int W, int Ho, int Wo, int ph, int pw, float *__restrict__ out)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)planes * Ho * Wo) return;
+    const int xo = (int)(idx % Wo), yo = (int)((idx / Wo) % Ho), pl = (int)(idx / ((size_t)Wo * Ho));
+    const float *p = in + (size_t)pl * H * W;
+    float s = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int yy = yo * 2 + dy - ph, xx = xo * 2 + dx - pw;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) s += p[(size_t)yy * W + xx];
+        }
+    out[idx] = s * 0.25f;
+}
+
+// level means -> relu -> weighted product per plane -> mean over planes
+__global__ void k_msssim_finalize(const float *__restrict__ part, const int *__restrict__ nblk, const float *__restrict__ nmap,
+                                  int planes, float *__restrict__ out)
+{
+    __shared__ double acc[64];
+    const float wts[5] = {0.0448f, 0.2856f, 0.3001f, 0.2363f, 0.1333f};
+    const int pl = threadIdx.x;
+    double val = 0.0;
+    if (pl < planes) {
+        size_t off = 0;
+        double prod = 1.0;
+        for (int lv = 0; lv < 5; ++lv) {
+            double ss = 0.0, cs = 0.0;
+            for (int b = 0; b < nblk[lv]; ++b) {
+                ss += (double)part[off + 2 * ((size_t)pl * nblk[lv] + b)];
+                cs += (double)part[off + 2 * ((size_t)pl * nblk[lv] + b) + 1];
+            }
+            off += (size_t)2 * planes * nblk[lv];
+            const double v = (lv < 4 ? cs : ss) / (double)nmap[lv];
+            prod *= pow(v > 0.0 ? v : 0.0, (double)wts[lv]);
+        }
+        val = prod;
+    }
+    acc[pl] = val;
+    __syncthreads();
+    if (pl == 0) {
+        double s = 0.0;
+        for (int i = 0; i < planes; ++i) s += acc[i];
+        out[0] = (float)(s / planes);
+    }
+}
+
+static void msssim_geom(int H, int W, int Hs[5], int Ws[5])
+{
+    Hs[0] = H; Ws[0] = W;
+    for (int l = 1; l < 5; ++l) { Hs[l] = (Hs[l - 1] + 2 * (Hs[l - 1] % 2)) / 2; Ws[l] = (Ws[l - 1] + 2 * (Ws[l - 1] % 2)) / 2; }
+}
+
+extern "C" size_t orn_msssim_ws_bytes(int B, int Ch, int H, int W)
+{
+    int Hs[5], Ws[5];
+    msssim_geom(H, W, Hs, Ws);
+    const size_t planes = (size_t)B * Ch;
+    size_t f = 64;                                       // level tables
+    for (int l = 1; l < 5; ++l) f += 2 * orn_align(planes * Hs[l] * Ws[l] * 4) / 4;
+    for (int l = 0; l < 5; ++l) f += orn_align(2 * planes * orn_cdiv(Ws[l] - 10, SS_TW) * orn_cdiv(Hs[l] - 10, SS_TH) * 4 + 8) / 4;
+    return f * 4;
+}
+
+// out[0] = ms_ssim(pred, target, data_range=1, size_average=True).  Needs min(H, W) > 160 (pytorch_msssim's own limit).
+extern "C" int orn_msssim(const float *pred, const float *target, int B, int Ch, int H, int W, float *out, void *ws,
+                          size_t ws_bytes, void *stream)
+{
+    ORN_REQUIRE(pred && target && out && ws, "msssim: null pointer");
+    ORN_REQUIRE(B > 0 && Ch > 0 && B * Ch <= 64, "msssim: bad plane count");
+    ORN_REQUIRE((H < W ? H : W) > 160, "msssim: image side must exceed 160 (got %dx%d)", H, W);
+    if (ws_bytes < orn_msssim_ws_bytes(B, Ch, H, W)) { orn_set_error("msssim: workspace too small"); return ORN_E_WS; }
+    ORN_TRY(ensure_gauss());
+    hipStream_t st = (hipStream_t)stream;
+    int Hs[5], Ws[5];
+    msssim_geom(H, W, Hs, Ws);
+    const int planes = B * Ch;
+    float *base = (float *)ws;
+    int *d_nblk = (int *)base;
+    float *d_nmap = base + 8;
+    float *cur = base + 64;
+    const float *x = pred, *y = target;
+    int h_nblk[5];
+    float h_nmap[5];
+    float *pooled[5][2] = {};
+    for (int l = 1; l < 5; ++l)
+        for (int k = 0; k < 2; ++k) { pooled[l][k] = cur; cur += orn_align((size_t)planes * Hs[l] * Ws[l] * 4) / 4; }
+    float *part = cur;
+    size_t poff = 0;
+    for (int l = 0; l < 5; ++l) {
+        const int tw = orn_cdiv(Ws[l] - 10, SS_TW), th = orn_cdiv(Hs[l] - 10, SS_TH);
+        h_nblk[l] = tw * th;
+        h_nmap[l] = (float)(Hs[l] - 10) * (float)(Ws[l] - 10);
+        hipLaunchKernelGGL(k_ssim_cs_partial, dim3(tw * th, planes), dim3(256), 0, st, x, y, Hs[l], Ws[l], tw, part + poff);
+        ORN_LAUNCH_CHECK("ssim_cs_partial");
+        poff += (size_t)2 * planes * h_nblk[l];
+        if (l < 4) {
+            const size_t n = (size_t)planes * Hs[l + 1] * Ws[l + 1];
+            hipLaunchKernelGGL(k_avgpool2, dim3(orn_cdiv((long)n, 256)), dim3(256), 0, st, x, planes, Hs[l], Ws[l], Hs[l + 1], Ws[l + 1],
+                               Hs[l] % 2, Ws[l] % 2, pooled[l + 1][0]);
+            hipLaunchKernelGGL(k_avgpool2, dim3(orn_cdiv((long)n, 256)), dim3(256), 0, st, y, planes, Hs[l], Ws[l], Hs[l + 1], Ws[l + 1],
+                               Hs[l] % 2, Ws[l] % 2, pooled[l + 1][1]);
+            ORN_LAUNCH_CHECK("avgpool2");
+            x = pooled[l + 1][0];
+            y = pooled[l + 1][1];
+        }
+    }
+    hipError_t rc = hipMemcpyAsync(d_nblk, h_nblk, sizeof(h_nblk), hipMemcpyHostToDevice, st);
+    if (rc == hipSuccess) rc = hipMemcpyAsync(d_nmap, h_nmap, sizeof(h_nmap), hipMemcpyHostToDevice, st);
+    if (rc == hipSuccess) rc = hipStreamSynchronize(st);        // tables live on the host stack (logging path, not graph-captured)
+    if (rc != hipSuccess) { orn_set_error("msssim: table upload failed: %s", hipGetErrorString(rc)); return (int)rc; }
+    hipLaunchKernelGGL(k_msssim_finalize, dim3(1), dim3(64), 0, st, part, d_nblk, d_nmap, planes, out);
+    ORN_LAUNCH_CHECK("msssim_finalize");
+    return 0;
+}

@@ -72,7 +72,9 @@ def main(argv=None):
     torch.cuda.synchronize()
     fps = n / (time.time() - t0)
     psnr = float(torch.stack(psnrs).mean())
-    msg = f'Eval: PSNR {psnr:.2f} dB, decode {fps:.1f} FPS, params {n_param / 1e6:.3f} M'
+    with torch.no_grad():                                            # untimed, as the FPS above is the decoder's
+        ms = [utils.msssim_fn([model(embeds[k:k + 1])[0]], [frames[k:k + 1]])[0, 0] for k in range(n)]
+    msg = f'Eval: PSNR {psnr:.2f} dB, MS-SSIM {float(torch.stack(ms).mean()):.4f}, decode {fps:.1f} FPS, params {n_param / 1e6:.3f} M'
     if bits is not None:
         msg += f', bpp {bits / (n * hw[0] * hw[1]):.4f}'
     print(msg)

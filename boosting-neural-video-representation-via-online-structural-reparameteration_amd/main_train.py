@@ -121,7 +121,8 @@ def evaluate(model, eng, args):
         psnrs.append(stats[4])
     torch.cuda.synchronize()
     dt = time.time() - t0
-    return float(torch.stack(psnrs).mean()), len(psnrs) / dt
+    ms = [utils.msssim_fn([eng.decode(eng.embeds[k])], [eng.frames[k:k + 1]])[0, 0] for k in range(0, n, args.test_gap)]  # untimed
+    return float(torch.stack(psnrs).mean()), len(psnrs) / dt, float(torch.stack(ms).mean())
 
 
 def train(args):
@@ -165,8 +166,8 @@ def train(args):
         print(line, file=log, flush=True)
         is_eval = (epoch + 1) % args.eval_freq == 0 or epoch > args.epochs - 10     # main_train.py:303
         if is_eval:
-            val_psnr, fps = evaluate(model, eng, args)
-            msg = f'Eval Epoch[{epoch + 1}] PSNR {val_psnr:.2f} decode FPS {fps:.1f}'
+            val_psnr, fps, val_msssim = evaluate(model, eng, args)
+            msg = f'Eval Epoch[{epoch + 1}] PSNR {val_psnr:.2f} MS-SSIM {val_msssim:.4f} decode FPS {fps:.1f}'
             print(msg, flush=True)
             print(msg, file=log, flush=True)
         if (args.ckpt_freq and (epoch + 1) % args.ckpt_freq == 0) or (not args.ckpt_freq and is_eval) or epoch == args.epochs - 1:

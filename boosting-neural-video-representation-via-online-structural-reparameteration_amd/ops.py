@@ -223,3 +223,15 @@ def adam_step_(p, g, m, v, lr: float, step: int, beta1: float = 0.5, beta2: floa
     n = p.numel()
     check(lib().orn_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), c_size_t(n), c_double(lr), c_double(beta1), c_double(beta2),
                               c_double(eps), c_int(step), stream()), 'orn_adam_step')
+
+
+# ---- N3 ------------------------------------------------------------------------------------
+def ms_ssim(pred, target) -> torch.Tensor:
+    """pytorch_msssim.ms_ssim(pred, target, data_range=1, size_average=True) as utils.py:205 calls it."""
+    pred, target = _f32c(pred.detach()), _f32c(target.detach())
+    B, Ch, H, W = pred.shape
+    out = torch.empty(1, device=pred.device)
+    nb = lib().orn_msssim_ws_bytes(B, Ch, H, W)
+    ws = _ws(nb, pred.device)
+    check(lib().orn_msssim(ptr(pred), ptr(target), B, Ch, H, W, ptr(out), ptr(ws), c_size_t(ws.numel()), stream()), 'orn_msssim')
+    return out[0]

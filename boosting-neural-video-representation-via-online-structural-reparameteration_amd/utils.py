@@ -45,6 +45,18 @@ def psnr_fn(output_list, target_list):
     return torch.cat(psnr_list, dim=1)
 
 
+def msssim_fn(output_list, target_list):
+    """utils.py:201-211: MS-SSIM per stage when H >= 160, else 0; expanded to [B, stages]."""
+    vals = []
+    for output, target in zip(output_list, target_list):
+        if output.size(-2) >= 160:
+            vals.append(ops.ms_ssim(output.float().detach(), target.detach()).view(1))
+        else:
+            vals.append(torch.zeros(1, device=output.device))
+    ms = torch.cat(vals, dim=0)
+    return ms.view(1, -1).expand(output_list[-1].size(0), -1)
+
+
 def lr_value(cur_epoch, cur_iter, data_size, args):
     """The multiplier arithmetic of utils.py:240-259, in Python doubles."""
     cur_epoch = cur_epoch + (float(cur_iter) / data_size)

@@ -131,6 +131,13 @@ size_t orn_loss_ws_bytes(int B, int Ch, int H, int W);
 int orn_loss_fwd_bwd(const float *pred, const float *target, int B, int Ch, int H, int W, int loss_type,
                      float loss_scale, float *stats, float *dpred, void *ws, size_t ws_bytes, void *stream);
 
+/* ---- N3  msssim_fn: pytorch_msssim.ms_ssim(pred, target, data_range=1, size_average=True)   utils.py:201-211
+ * Logging metric of the reference's train/eval loops (main_train.py:254); synchronises the stream (not for the
+ * captured training step).  out: one device float.  min(H, W) must exceed 160. */
+size_t orn_msssim_ws_bytes(int B, int Ch, int H, int W);
+int orn_msssim(const float *pred, const float *target, int B, int Ch, int H, int W, float *out, void *ws,
+               size_t ws_bytes, void *stream);
+
 /* ---- A9  optim.Adam.step over one flat arena                          main_train.py:196,250 ---
  * p,g,m,v: n floats each.  step = 1-based global step.  weight decay 0, amsgrad off.
  * Hyper-parameters are doubles (as Python holds them): 1-beta, lr/(1-beta1^t) and sqrt(1-beta2^t)

@@ -254,6 +254,24 @@ def test_loss_golden_plain(orn, golden):
         np.testing.assert_allclose(ps, g[f'psnr/{i}/out'], rtol=2e-6)
 
 
+# ---------------------------------------------------------------- N3 --------------------------
+@pytest.mark.parametrize('B,H,W', [(1, 180, 320), (2, 161, 177), (1, 720, 1280)])
+def test_msssim(orn, B, H, W):
+    """msssim_fn (utils.py:201-211) vs the oracle's restatement of pytorch_msssim.ms_ssim (parity unpinned: the
+    package is not in the reference tree).  fp32 tolerance 2e-5 absolute on a value in [0, 1]."""
+    from oracle import cpu_ref
+    gen = torch.Generator().manual_seed(H + W)
+    t = torch.rand(B, 3, H, W, generator=gen)
+    t = torch.nn.functional.avg_pool2d(t, 5, 1, 2)                     # some structure so cs is not ~0
+    p = (t + 0.05 * torch.randn(B, 3, H, W, generator=gen)).clamp(0, 1)
+    ref = cpu_ref.ms_ssim(p.double(), t.double()).item()
+    out = orn.utils.msssim_fn([cu(p)], [cu(t)])
+    assert out.shape == (B, 1)
+    assert abs(out[0, 0].item() - ref) <= 2e-5, (out[0, 0].item(), ref)
+    small = orn.utils.msssim_fn([cu(p[..., :100, :100])], [cu(t[..., :100, :100])])
+    assert float(small.abs().max()) == 0.0                              # H < 160 -> 0, as the reference
+
+
 # ---------------------------------------------------------------- A9 --------------------------
 def test_adam(orn):
     from oracle import cpu_ref
