@@ -37,17 +37,17 @@ def layer_geo():
     return out
 
 
-def make_engine(seed, precision, branch_type='ERB', noise=0.1):
+def make_engine(seed, precision, branch_type='ERB', noise=0.1, fc_hw_dim=None, strides=None, hw=(720, 1280), frames=None):
     from orn_amd import engine, model, ops
     from orn_amd.data import synthetic_video
     torch.manual_seed(1)                                    # main_train.py:162
-    gen = model.Generator(embed_length=80, stem_dim_num=CFG['stem_dim_num'], fc_hw_dim=CFG['fc_hw_dim'],
+    gen = model.Generator(embed_length=80, stem_dim_num=CFG['stem_dim_num'], fc_hw_dim=fc_hw_dim or CFG['fc_hw_dim'],
                           expansion=CFG['expansion'], num_blocks=1, norm='none', act='swish', bias=True,
-                          reduction=CFG['reduction'], conv_type='conv', stride_list=CFG['strides'], sin_res=True,
+                          reduction=CFG['reduction'], conv_type='conv', stride_list=strides or CFG['strides'], sin_res=True,
                           lower_width=CFG['lower_width'], sigmoid=False, deploy=False, branch_type=branch_type)
     eng = engine.TrainEngine(gen, loss_type=CFG['loss'], beta=CFG['beta'], precision=precision)
-    n = CFG['frames']
-    frames = synthetic_video(n, 720, 1280, seed=seed, device=eng.device, noise=noise)
+    n = frames or CFG['frames']
+    frames = synthetic_video(n, hw[0], hw[1], seed=seed, device=eng.device, noise=noise)
     pos = torch.tensor([float(k) / n for k in range(n)], dtype=torch.float32)
     embeds = ops.pe_forward(pos.to(eng.device), 1.25, 40)
     eng.set_video(frames, embeds)

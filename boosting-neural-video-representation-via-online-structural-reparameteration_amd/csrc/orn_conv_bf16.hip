@@ -590,8 +590,9 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p)
 }
 
 // dWf[o][c][i][j] = gscale * sum_s slabs[s][tap][o'(o)][c],  o' = (o % s2)*Cn + o / s2
+// Cr <= 96 real input channels (a narrower first fast layer runs zero-padded to 96): only those are written
 __global__ void k_wgrad_bf16_reduce(const float *__restrict__ slabs, const float *__restrict__ bias_slabs, int S, int O, int Cn,
-                                    int s2, float gscale, float *__restrict__ dwf, float *__restrict__ dbf)
+                                    int s2, int Cr, float gscale, float *__restrict__ dwf, float *__restrict__ dbf)
 {
     const size_t n = (size_t)9 * O * 96;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -602,6 +603,8 @@ __global__ void k_wgrad_bf16_reduce(const float *__restrict__ slabs, const float
         dbf[nn * s2 + ij] = b * gscale;
     }
     if (idx >= n) return;
+    const int c = (int)(idx % 96);
+    if (c >= Cr) return;
     // 8 independent partial sums keep 8 loads in flight (fixed order -> still deterministic)
     float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int s = 0;
@@ -611,22 +614,21 @@ __global__ void k_wgrad_bf16_reduce(const float *__restrict__ slabs, const float
     }
     for (; s < S; ++s) a8[0] += slabs[(size_t)s * n + idx];
     const float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
-    const int c = (int)(idx % 96);
     const size_t r = idx / 96;
     const int op = (int)(r % O), tap = (int)(r / O);
     const int ij = op / Cn, nn = op - ij * Cn;
     const int o = nn * s2 + ij;
-    dwf[((size_t)o * 96 + c) * 9 + tap] = acc * gscale;
+    dwf[((size_t)o * Cr + c) * 9 + tap] = acc * gscale;
 }
 
 int orn_wgrad_bf16_split(int H, int W, int O)
 {
-    // S slabs of 9*O*96 floats are written and re-read: keep >= 16 K tiles per work-group so the slab traffic
+    // S slabs of 9*O*96 floats are written and re-read: keep >= 8 K tiles per work-group so the slab traffic
     // stays small next to the layer's own data, up to one full wave of work-groups (2 per CU)
     const int n_ktiles = orn_cdiv(H, WB_TH) * orn_cdiv(W, WB_TW);
     const int per = 3 * (O / WB_BO);
     int S = (512 / per) / 8 * 8;
-    const int by_work = (n_ktiles / 16) / 8 * 8;
+    const int by_work = (n_ktiles / 8) / 8 * 8;
     if (S > by_work) S = by_work;
     if (S < 8) S = 8;
     return S;
@@ -634,11 +636,12 @@ int orn_wgrad_bf16_split(int H, int W, int O)
 
 size_t orn_wgrad_bf16_ws_floats(int H, int W, int O) { return (size_t)orn_wgrad_bf16_split(H, W, O) * (9 * (size_t)O * 96 + O); }
 
-// dwf [O][96][3][3] and dbf [O] (PyTorch channel order), both overwritten.
+// dwf [O][C][3][3] and dbf [O] (PyTorch channel order), both overwritten.  C <= 96 real channels; xpad always has 96
+// channels per pixel (zeros above C).
 int orn_launch_wgrad_bf16(const h16 *xpad, const h16 *dypad, int H, int W, int C, int O, int s, float gscale,
                           float *slabs, float *dwf, float *dbf, hipStream_t st)
 {
-    ORN_REQUIRE(C == 96 && O % WB_BO == 0 && O % (s * s) == 0, "wgrad_bf16: unsupported C=%d O=%d", C, O);
+    ORN_REQUIRE(C >= 1 && C <= 96 && O % WB_BO == 0 && O % (s * s) == 0, "wgrad_bf16: unsupported C=%d O=%d", C, O);
     WgradBP p;
     p.dbg = g_conv_dbg;
     p.xpad = xpad; p.dypad = dypad; p.slabs = slabs; p.H = H; p.W = W; p.O = O;
@@ -658,7 +661,7 @@ int orn_launch_wgrad_bf16(const h16 *xpad, const h16 *dypad, int H, int W, int C
     ORN_LAUNCH_CHECK("wgrad_nhwc_bf16");
     const size_t n = (size_t)9 * O * 96;
     hipLaunchKernelGGL(k_wgrad_bf16_reduce, dim3(orn_cdiv((long)n, 256)), dim3(256), 0, st, slabs, p.bias_slabs, p.S, O,
-                       O / (s * s), s * s, gscale, dwf, dbf);
+                       O / (s * s), s * s, C, gscale, dwf, dbf);
     ORN_LAUNCH_CHECK("wgrad_bf16_reduce");
     return 0;
 }
@@ -688,7 +691,7 @@ __global__ void k_prep_weights_bf16(const float *__restrict__ wf, const float *_
 
 struct PrepAll {
     int n;
-    struct { const float *wf, *bf; int O, C, Cn, s2; h16 *wb, *wd; float *biasp; } l[ORN_MAX_LAYERS];
+    struct { const float *wf, *bf; int O, C, Cp, Cn, s2; h16 *wb, *wd; float *biasp; } l[ORN_MAX_LAYERS];   // Cp: channel stride
 };
 
 __global__ void k_prep_weights_bf16_all(PrepAll a)
@@ -705,8 +708,8 @@ __global__ void k_prep_weights_bf16_all(PrepAll a)
     const int c = (int)(oc % l.C), o = (int)(oc / l.C);
     const int op = (o % l.s2) * l.Cn + o / l.s2;
     const h16 v = (h16)l.wf[idx];
-    l.wb[((size_t)tap * l.O + op) * l.C + c] = v;
-    l.wd[((size_t)(8 - tap) * l.C + c) * l.O + op] = v;
+    l.wb[((size_t)tap * l.O + op) * l.Cp + c] = v;
+    l.wd[((size_t)(8 - tap) * l.Cp + c) * l.O + op] = v;
 }
 
 int orn_launch_prep_weights_bf16_all(int n, const OrnPrepLayer *L, hipStream_t st)
@@ -717,6 +720,7 @@ int orn_launch_prep_weights_bf16_all(int n, const OrnPrepLayer *L, hipStream_t s
     size_t mx = 0;
     for (int i = 0; i < n; ++i) {
         a.l[i].wf = L[i].wf; a.l[i].bf = L[i].bf; a.l[i].O = L[i].O; a.l[i].C = L[i].C;
+        a.l[i].Cp = L[i].Cp > 0 ? L[i].Cp : L[i].C;
         a.l[i].Cn = L[i].O / (L[i].s * L[i].s); a.l[i].s2 = L[i].s * L[i].s;
         a.l[i].wb = (h16 *)L[i].wb; a.l[i].wd = (h16 *)L[i].wd; a.l[i].biasp = L[i].biasp;
         const size_t w = (size_t)L[i].O * L[i].C * 9;
@@ -736,11 +740,12 @@ int orn_launch_prep_weights_bf16(const float *wf, const float *bf, int O, int C,
     return 0;
 }
 
-// fp32 NCHW [C][H][W] -> bf16 padded NHWC [H+2][W+2][C] interior (border stays zero).
+// fp32 NCHW [C][H][W] -> bf16 padded NHWC [H+2][W+2][Cp] interior, channels [0, C) (border and channels >= C stay zero).
 // 64-pixel x C tile through LDS: coalesced along pixels on the read, along channels on the write.
 #define TR_PX 16
 #define TR_MAXC 128
-__global__ void __launch_bounds__(256) k_nchw_to_nhwc_pad_bf16(const float *__restrict__ src, int C, int H, int W, h16 *__restrict__ dst)
+__global__ void __launch_bounds__(256) k_nchw_to_nhwc_pad_bf16(const float *__restrict__ src, int C, int Cp, int H, int W,
+                                                              h16 *__restrict__ dst)
 {
     __shared__ float tile[TR_MAXC][TR_PX + 1];
     const size_t HW = (size_t)H * W;
@@ -755,23 +760,23 @@ __global__ void __launch_bounds__(256) k_nchw_to_nhwc_pad_bf16(const float *__re
         const size_t pix = p0 + px;
         if (pix < HW) {
             const int h = (int)(pix / W), w = (int)(pix - (size_t)h * W);
-            dst[((size_t)(h + 1) * (W + 2) + (w + 1)) * C + c] = (h16)tile[c][px];
+            dst[((size_t)(h + 1) * (W + 2) + (w + 1)) * Cp + c] = (h16)tile[c][px];
         }
     }
 }
 
-// fp32 NHWC slabs [nslab][H][W][C] -> fp32 NCHW [C][H][W] (sum over slabs in fixed order), tiled through LDS
-__global__ void __launch_bounds__(256) k_nhwc_to_nchw_f32(const float *__restrict__ src, int C, int H, int W, int nslab, float scale,
-                                                         float *__restrict__ dst)
+// fp32 NHWC slabs [nslab][H][W][Cp] -> fp32 NCHW [C][H][W], C <= Cp (sum over slabs in fixed order), tiled through LDS
+__global__ void __launch_bounds__(256) k_nhwc_to_nchw_f32(const float *__restrict__ src, int C, int Cp, int H, int W, int nslab,
+                                                         float scale, float *__restrict__ dst)
 {
     __shared__ float tile[TR_MAXC][TR_PX + 1];
-    const size_t HW = (size_t)H * W, n = HW * C;
+    const size_t HW = (size_t)H * W, n = HW * Cp;
     const size_t p0 = (size_t)blockIdx.x * TR_PX;
     for (int idx = threadIdx.x; idx < C * TR_PX; idx += 256) {
         const int px = idx / C, c = idx - px * C;
         float v = 0.f;
         if (p0 + px < HW)
-            for (int s = 0; s < nslab; ++s) v += src[(size_t)s * n + (p0 + px) * C + c];
+            for (int s = 0; s < nslab; ++s) v += src[(size_t)s * n + (p0 + px) * Cp + c];
         tile[c][px] = v * scale;
     }
     __syncthreads();
@@ -781,18 +786,18 @@ __global__ void __launch_bounds__(256) k_nhwc_to_nchw_f32(const float *__restric
     }
 }
 
-int orn_launch_nchw_to_nhwc_pad_bf16(const float *src, int C, int H, int W, h16 *dst, hipStream_t st)
+int orn_launch_nchw_to_nhwc_pad_bf16(const float *src, int C, int Cp, int H, int W, h16 *dst, hipStream_t st)
 {
-    ORN_REQUIRE(C <= TR_MAXC, "nchw_to_nhwc: C=%d > %d", C, TR_MAXC);
-    hipLaunchKernelGGL(k_nchw_to_nhwc_pad_bf16, dim3(orn_cdiv((long)H * W, TR_PX)), dim3(256), 0, st, src, C, H, W, dst);
+    ORN_REQUIRE(C <= TR_MAXC && C <= Cp, "nchw_to_nhwc: C=%d > %d or > stride %d", C, TR_MAXC, Cp);
+    hipLaunchKernelGGL(k_nchw_to_nhwc_pad_bf16, dim3(orn_cdiv((long)H * W, TR_PX)), dim3(256), 0, st, src, C, Cp, H, W, dst);
     ORN_LAUNCH_CHECK("nchw_to_nhwc_pad_bf16");
     return 0;
 }
 
-int orn_launch_nhwc_to_nchw_f32(const float *src, int C, int H, int W, int nslab, float scale, float *dst, hipStream_t st)
+int orn_launch_nhwc_to_nchw_f32(const float *src, int C, int Cp, int H, int W, int nslab, float scale, float *dst, hipStream_t st)
 {
-    ORN_REQUIRE(C <= TR_MAXC, "nhwc_to_nchw: C=%d > %d", C, TR_MAXC);
-    hipLaunchKernelGGL(k_nhwc_to_nchw_f32, dim3(orn_cdiv((long)H * W, TR_PX)), dim3(256), 0, st, src, C, H, W, nslab, scale, dst);
+    ORN_REQUIRE(C <= TR_MAXC && C <= Cp, "nhwc_to_nchw: C=%d > %d or > stride %d", C, TR_MAXC, Cp);
+    hipLaunchKernelGGL(k_nhwc_to_nchw_f32, dim3(orn_cdiv((long)H * W, TR_PX)), dim3(256), 0, st, src, C, Cp, H, W, nslab, scale, dst);
     ORN_LAUNCH_CHECK("nhwc_to_nchw_f32");
     return 0;
 }
@@ -975,11 +980,26 @@ k_head_bwd_nhwc_bf16(const h16 *__restrict__ z, const float *__restrict__ w, con
     }
 }
 
-__global__ void k_head_bf16_finish(const float *__restrict__ red, int C, float gscale, float *__restrict__ dw, float *__restrict__ db)
+// dw/db = gscale * sum over blocks of the per-block partials [blocks][3C+3]: one work-group per column, lane t sums
+// rows t, t+256, .. in ascending order, fixed-order block tree after (deterministic).
+__global__ void __launch_bounds__(256) k_head_bf16_finish(const float *__restrict__ partial, int blocks, int C, float gscale,
+                                                          float *__restrict__ dw, float *__restrict__ db)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 3 * C) dw[i] = red[i] * gscale;
-    else if (i < 3 * C + 3) db[i - 3 * C] = red[i] * gscale;
+    __shared__ float sred[256];
+    const int n = 3 * C + 3, col = blockIdx.x, t = threadIdx.x;
+    float acc = 0.f;
+    for (int r = t; r < blocks; r += 256) acc += partial[(size_t)r * n + col];
+    sred[t] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) sred[t] += sred[t + w];
+        __syncthreads();
+    }
+    if (t == 0) {
+        const float v = sred[0] * gscale;
+        if (col < 3 * C) dw[col] = v;
+        else db[col - 3 * C] = v;
+    }
 }
 
 #define HB_BLOCKS 512
@@ -1013,8 +1033,8 @@ int orn_launch_head_bwd_bf16(const h16 *z, const float *w, const float *out, con
     }
     ORN_LAUNCH_CHECK("head_bwd_bf16");
     const size_t n = 3 * (size_t)C + 3;
-    ORN_TRY(orn_launch_reduce_rows(partial, blocks, n, n, red, st));
-    hipLaunchKernelGGL(k_head_bf16_finish, dim3(orn_cdiv((long)n, 128)), dim3(128), 0, st, red, C, 1.0f / gs_up, dw, db);
+    (void)red;
+    hipLaunchKernelGGL(k_head_bf16_finish, dim3((unsigned)n), dim3(256), 0, st, partial, blocks, C, 1.0f / gs_up, dw, db);
     ORN_LAUNCH_CHECK("head_bf16_finish");
     return 0;
 }
@@ -1029,8 +1049,8 @@ static int a_conv_dgrad(const void *dypad, const void *wd, int H, int W, int O, 
 static int a_wgrad(const void *xpad, const void *dypad, int H, int W, int C, int O, int s, float gscale, float *slabs, float *dwf,
                    float *dbf, hipStream_t st)
 { return orn_launch_wgrad_bf16((const h16 *)xpad, (const h16 *)dypad, H, W, C, O, s, gscale, slabs, dwf, dbf, st); }
-static int a_to_nhwc(const float *src, int C, int H, int W, void *dst, hipStream_t st)
-{ return orn_launch_nchw_to_nhwc_pad_bf16(src, C, H, W, (h16 *)dst, st); }
+static int a_to_nhwc(const float *src, int C, int Cp, int H, int W, void *dst, hipStream_t st)
+{ return orn_launch_nchw_to_nhwc_pad_bf16(src, C, Cp, H, W, (h16 *)dst, st); }
 static int a_head_fwd(const void *z, const float *w, const float *b, int C, size_t HW, int sigmoid, float *out, hipStream_t st)
 { return orn_launch_head_fwd_bf16((const h16 *)z, w, b, C, HW, sigmoid, out, st); }
 static int a_head_bwd(const void *z, const float *w, const float *out, const float *dout, int C, int H, int W, int sigmoid, int sp,
@@ -1127,7 +1147,7 @@ extern "C" int orn_conv3x3_ps_silu_fwd_bf16(const float *x, const float *wf, con
     hipStream_t st = (hipStream_t)stream;
     const Bf16Ws b = carve_bf16(ws, C, O, H, W, s);
     const int Cn = O / (s * s), Hs = H * s, Ws = W * s;
-    ORN_TRY(orn_launch_nchw_to_nhwc_pad_bf16(x, C, H, W, b.xpad, st));
+    ORN_TRY(orn_launch_nchw_to_nhwc_pad_bf16(x, C, C, H, W, b.xpad, st));
     ORN_TRY(orn_launch_prep_weights_bf16(wf, bf, O, C, s, b.wb, b.wd, b.biasp, st));
     ORN_TRY(orn_launch_conv_bf16_fwd(b.xpad, b.wb, b.biasp, H, W, C, O, s, b.zb, b.apad, st));
     const long n = (long)Cn * Hs * Ws;
@@ -1147,7 +1167,7 @@ extern "C" int orn_conv3x3_ps_silu_bwd_bf16(const float *x, const float *wf, con
     hipStream_t st = (hipStream_t)stream;
     const Bf16Ws b = carve_bf16(ws, C, O, H, W, s);
     const int Cn = O / (s * s);
-    ORN_TRY(orn_launch_nchw_to_nhwc_pad_bf16(x, C, H, W, b.xpad, st));
+    ORN_TRY(orn_launch_nchw_to_nhwc_pad_bf16(x, C, C, H, W, b.xpad, st));
     ORN_TRY(orn_launch_prep_weights_bf16(wf, dbf /*scratch: overwritten below*/, O, C, s, b.wb, b.wd, b.biasp, st));
     const long n = (long)Cn * H * s * W * s;
     hipLaunchKernelGGL(k_make_dy_bf16, dim3(orn_cdiv(n, 256)), dim3(256), 0, st, z, da, Cn, H, W, s, b.zb, b.dypad);
@@ -1155,7 +1175,7 @@ extern "C" int orn_conv3x3_ps_silu_bwd_bf16(const float *x, const float *wf, con
     ORN_TRY(orn_launch_wgrad_bf16(b.xpad, b.dypad, H, W, C, O, s, 1.0f, b.slabs, dwf, dbf, st));
     if (dx) {
         ORN_TRY(orn_launch_conv_bf16_dgrad(b.dypad, b.wd, H, W, O, C, nullptr, nullptr, 1, b.dxn, st));
-        ORN_TRY(orn_launch_nhwc_to_nchw_f32(b.dxn, C, H, W, orn_dgrad_f32_slabs(H, W, O), 1.0f, dx, st));
+        ORN_TRY(orn_launch_nhwc_to_nchw_f32(b.dxn, C, C, H, W, orn_dgrad_f32_slabs(H, W, O), 1.0f, dx, st));
     }
     return 0;
 }

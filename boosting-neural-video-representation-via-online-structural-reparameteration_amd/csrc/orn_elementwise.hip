@@ -40,32 +40,34 @@ __global__ void k_reduce_rows(const float *__restrict__ in, int rows, size_t ld,
     out[j] = acc;
 }
 
-// Many rows, few columns: 32 columns x 8 row-lanes per block; each lane sums rows r = lane (mod 8) in
-// ascending order, then the 8 lane sums are added in fixed order through LDS.  Deterministic.
-__global__ void __launch_bounds__(256) k_reduce_rows_tall(const float *__restrict__ in, int rows, size_t ld, size_t n,
-                                                         float *__restrict__ out)
+// Many rows, few columns: 32 columns x 32 row-lanes per block; each lane sums rows r = lane (mod 32) in
+// ascending order, then the 32 lane sums are added in fixed order through LDS.  Deterministic.
+__global__ void __launch_bounds__(1024) k_reduce_rows_tall(const float *__restrict__ in, int rows, size_t ld, size_t n,
+                                                          float *__restrict__ out)
 {
-    __shared__ float sm[8][33];
+    __shared__ float sm[32][33];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const size_t j = (size_t)blockIdx.x * 32 + cx;
     float acc = 0.f;
     if (j < n)
-        for (int i = ry; i < rows; i += 8) acc += in[(size_t)i * ld + j];
+        for (int i = ry; i < rows; i += 32) acc += in[(size_t)i * ld + j];
     sm[ry][cx] = acc;
     __syncthreads();
-    if (ry == 0 && j < n) {
+    if (ry < 4) {                                   // 4 partial sums of 8 lanes each, then a fixed 4-way add
         float r = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) r += sm[k][cx];
-        out[j] = r;
+        for (int k = 0; k < 8; ++k) r += sm[ry * 8 + k][cx];
+        sm[ry * 8][cx] = r;
     }
+    __syncthreads();
+    if (ry == 0 && j < n) out[j] = (sm[0][cx] + sm[8][cx]) + (sm[16][cx] + sm[24][cx]);
 }
 
 int orn_launch_reduce_rows(const float *in, int rows, size_t ld, size_t n, float *out, hipStream_t st)
 {
     if (n == 0) return 0;
     if (rows >= 32 && n <= 65536) {
-        hipLaunchKernelGGL(k_reduce_rows_tall, dim3(orn_cdiv((long)n, 32)), dim3(256), 0, st, in, rows, ld, n, out);
+        hipLaunchKernelGGL(k_reduce_rows_tall, dim3(orn_cdiv((long)n, 32)), dim3(1024), 0, st, in, rows, ld, n, out);
         ORN_LAUNCH_CHECK("reduce_rows_tall");
         return 0;
     }

@@ -76,9 +76,10 @@ static int check_desc(const orn_engine_desc *d)
 }
 
 // Computes the workspace layout (in floats); if e != null also fills its pointers.
+#define ORN_FAST_C 96          // input channels per pixel of every 16-bit channels-last buffer
 static bool layer_is_fast(const orn_layer_desc &l)
 {
-    return l.C == 96 && l.O % 128 == 0 && l.O % (l.s * l.s) == 0;
+    return l.C == ORN_FAST_C && l.O % 128 == 0 && l.O % (l.s * l.s) == 0;
 }
 
 // First layer from which every layer (and the head) can run on the bf16 MFMA path.
@@ -90,6 +91,12 @@ static int first_fast_layer(const orn_engine_desc *d)
     if (!(cn == 32 || cn == 64 || cn == 96 || cn == 128)) return d->n_layers;
     int ff = d->n_layers;
     while (ff > 0 && layer_is_fast(d->layer[ff - 1])) --ff;
+    // one narrower layer below them may join, zero-padded to 96 input channels (its fp32 NCHW input is converted
+    // anyway): 3.7x the FLOPs of C=26 on a 16x faster pipe, and none of the fp32 path's small launches
+    if (ff > 0 && ff < d->n_layers) {
+        const orn_layer_desc &l = d->layer[ff - 1];
+        if (l.C < ORN_FAST_C && l.O % 128 == 0 && l.O % (l.s * l.s) == 0) --ff;
+    }
     return ff;
 }
 
@@ -120,14 +127,15 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
             s1 = orn_conv3x3_ps_silu_bwd_ws_bytes(1, l.C, l.O, l.H, l.W) / 4;
         } else {
             // halfs are carved as floats (2 per float)
-            L[i].xpad = (uint16_t *)take(((size_t)(l.H + 2) * (l.W + 2) * l.C + 1) / 2);
+            const size_t wpz = (size_t)l.O * ORN_FAST_C * 9;
+            L[i].xpad = (uint16_t *)take(((size_t)(l.H + 2) * (l.W + 2) * ORN_FAST_C + 1) / 2);
             L[i].zb = (uint16_t *)take((asz + 1) / 2);
             L[i].dypad = (uint16_t *)take(((size_t)(l.H + 2) * (l.W + 2) * l.O + 1) / 2);
-            L[i].wb = (uint16_t *)take((wsz + 1) / 2);
-            L[i].wd = (uint16_t *)take((wsz + 1) / 2);
+            L[i].wb = (uint16_t *)take((wpz + 1) / 2);
+            L[i].wd = (uint16_t *)take((wpz + 1) / 2);
             L[i].biasp = take(l.O);
             const OrnHalfOps *ops = orn_half_ops_bf16();     // sizes do not depend on the element type
-            if (i == ff) dxn = take((size_t)l.H * l.W * l.C * ops->dgrad_f32_slabs(l.H, l.W, l.O));
+            if (i == ff) dxn = take((size_t)l.H * l.W * ORN_FAST_C * ops->dgrad_f32_slabs(l.H, l.W, l.O));
             s1 = al(ops->wgrad_ws_floats(l.H, l.W, l.O));
         }
         if (d->erb) { const size_t s2 = orn_erb_merge_bwd_ws_bytes(l.C, l.O) / 4; if (s2 > s1) s1 = s2; }
@@ -248,18 +256,6 @@ __global__ void k_advance(const orn_step_sched *__restrict__ sched, int32_t *cur
     }
 }
 
-__global__ void k_publish_stats(const float *__restrict__ stats, const OrnStepCur *cur, float *ring)
-{
-    const int t = threadIdx.x;
-    if (t < 8) {
-        float v = stats[t];
-        if (t == 5) v = cur->lr;
-        if (t == 6) v = (float)cur->frame;
-        if (t == 7) v = (float)cur->step;
-        ring[(size_t)cur->slot * 8 + t] = v;
-    }
-}
-
 static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool keep_z, hipStream_t st)
 {
     const orn_engine_desc &d = e->d;
@@ -287,7 +283,7 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
         OrnPrepLayer pl[ORN_MAX_LAYERS];
         for (int i = ff; i < nl; ++i) {
             const orn_layer_desc &l = d.layer[i];
-            pl[i - ff] = OrnPrepLayer{e->L[i].wf, e->L[i].bf, l.O, l.C, l.s, e->L[i].wb, e->L[i].wd, e->L[i].biasp};
+            pl[i - ff] = OrnPrepLayer{e->L[i].wf, e->L[i].bf, l.O, l.C, l.s, e->L[i].wb, e->L[i].wd, e->L[i].biasp, ORN_FAST_C};
         }
         ORN_TRY(e->ops->prep_all(nl - ff, pl, st));
     }
@@ -298,8 +294,8 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
             ORN_TRY(orn_launch_conv3x3_f32(x, b.wf, b.bf, 1, l.C, l.O, l.H, l.W, l.s, 1, keep_z ? b.z : nullptr, b.a, st, nullptr));
             x = b.a;
         } else {
-            if (i == ff) ORN_TRY(e->ops->to_nhwc(x, l.C, l.H, l.W, b.xpad, st));
-            ORN_TRY(e->ops->conv_fwd(b.xpad, b.wb, b.biasp, l.H, l.W, l.C, l.O, l.s, b.zb, (i + 1 < nl) ? e->L[i + 1].xpad : nullptr, st));
+            if (i == ff) ORN_TRY(e->ops->to_nhwc(x, l.C, ORN_FAST_C, l.H, l.W, b.xpad, st));
+            ORN_TRY(e->ops->conv_fwd(b.xpad, b.wb, b.biasp, l.H, l.W, ORN_FAST_C, l.O, l.s, b.zb, (i + 1 < nl) ? e->L[i + 1].xpad : nullptr, st));
         }
     }
     if (ff < nl)
@@ -331,11 +327,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
     const int *fidx = &e->cur->frame;
     ORN_TRY(forward(e, embeds, fidx, true, st));
     ORN_TRY(orn_launch_loss(e->img, frames, fidx, 3 * HWo, 1, 3, e->Hout, e->Wout, d.loss_type, 1.0f, e->stats, e->dimg,
-                            e->loss_ws, st));
-    if (stats_out) {
-        hipLaunchKernelGGL(k_publish_stats, dim3(1), dim3(64), 0, st, e->stats, e->cur, stats_out);
-        ORN_LAUNCH_CHECK("publish_stats");
-    }
+                            e->loss_ws, st, e->cur, stats_out));
     const int nl = d.n_layers, ff = e->ff;
     if (ff < nl)
         ORN_TRY(e->ops->head_bwd(e->L[nl - 1].zb, P + d.head_w, e->img, e->dimg, e->Cn_last, e->Hout, e->Wout, d.sigmoid,
@@ -355,8 +347,9 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
                 ORN_TRY(e->ops->conv_dgrad(b.dypad, b.wd, l.H, l.W, l.O, l.C, e->L[i - 1].zb, e->L[i - 1].dypad, d.layer[i - 1].s,
                                            nullptr, st));
             } else {
-                ORN_TRY(e->ops->conv_dgrad(b.dypad, b.wd, l.H, l.W, l.O, l.C, nullptr, nullptr, 1, e->dxn, st));
-                ORN_TRY(e->ops->to_nchw_f32(e->dxn, l.C, l.H, l.W, e->ops->dgrad_f32_slabs(l.H, l.W, l.O), 1.0f / e->gs, dx, st));
+                ORN_TRY(e->ops->conv_dgrad(b.dypad, b.wd, l.H, l.W, l.O, ORN_FAST_C, nullptr, nullptr, 1, e->dxn, st));
+                ORN_TRY(e->ops->to_nchw_f32(e->dxn, l.C, ORN_FAST_C, l.H, l.W, e->ops->dgrad_f32_slabs(l.H, l.W, l.O), 1.0f / e->gs, dx,
+                                            st));
             }
         } else
         ORN_TRY(orn_launch_conv_bwd_f32(x, b.wf, b.z, b.da, 1, l.C, l.O, l.H, l.W, l.s, dx, G + l.w3x3, G + l.b3x3, e->scratch, st));

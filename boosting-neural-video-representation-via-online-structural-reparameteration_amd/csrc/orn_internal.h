@@ -60,11 +60,11 @@ int orn_launch_conv_bwd_f32(const float *x, const float *wf, const float *z, con
 int orn_loss_init();
 int orn_launch_loss(const float *pred, const float *target, const int *frame_idx, size_t frame_stride, int B, int Ch,
                     int H, int W, int loss_type, float loss_scale, float *stats, float *dpred, float *ws,
-                    hipStream_t st);
+                    hipStream_t st, const OrnStepCur *cur = nullptr, float *ring = nullptr);
 
 // orn_conv_bf16.hip: the 16-bit MFMA fast path (channels-last buffers, see the file header).  The file is built
 // twice (bf16 and, with -DORN_FP16, IEEE half); the engine reaches either build through this type-erased table.
-struct OrnPrepLayer { const float *wf, *bf; int O, C, s; void *wb, *wd; float *biasp; };
+struct OrnPrepLayer { const float *wf, *bf; int O, C, s; void *wb, *wd; float *biasp; int Cp; };   // Cp: channel stride (0: = C)
 struct OrnHalfOps {
     int (*conv_fwd)(const void *xpad, const void *wb, const float *bias_p, int H, int W, int Cin, int O, int s, void *z, void *apad,
                     hipStream_t st);
@@ -74,8 +74,8 @@ struct OrnHalfOps {
     int (*wgrad)(const void *xpad, const void *dypad, int H, int W, int C, int O, int s, float gscale, float *slabs, float *dwf,
                  float *dbf, hipStream_t st);
     int (*prep_all)(int n, const OrnPrepLayer *L, hipStream_t st);
-    int (*to_nhwc)(const float *src, int C, int H, int W, void *dst, hipStream_t st);
-    int (*to_nchw_f32)(const float *src, int C, int H, int W, int nslab, float scale, float *dst, hipStream_t st);
+    int (*to_nhwc)(const float *src, int C, int Cp, int H, int W, void *dst, hipStream_t st);
+    int (*to_nchw_f32)(const float *src, int C, int Cp, int H, int W, int nslab, float scale, float *dst, hipStream_t st);
     int (*dgrad_f32_slabs)(int H, int W, int O);
     int (*head_fwd)(const void *z, const float *w, const float *b, int C, size_t HW, int sigmoid, float *out, hipStream_t st);
     size_t (*head_bwd_ws_floats)(int C);

@@ -235,7 +235,8 @@ __global__ void __launch_bounds__(256) k_loss_grad(LossP q)
 // One block; fixed-order strided partial sums in double, then a fixed tree.
 __global__ void __launch_bounds__(1024)
 k_loss_finalize(const float *__restrict__ part_ssim, int n_ssim, const float *__restrict__ part_l1, int n_l1,
-                double n_elem, double n_map, int loss_type, float loss_scale, float *__restrict__ stats)
+                double n_elem, double n_map, int loss_type, float loss_scale, float *__restrict__ stats,
+                const OrnStepCur *__restrict__ cur, float *__restrict__ ring)
 {
     __shared__ double sd[3][1024];
     const int t = threadIdx.x;
@@ -262,6 +263,11 @@ k_loss_finalize(const float *__restrict__ part_ssim, int n_ssim, const float *__
         stats[3] = ss;
         stats[4] = -10.0f * log10f(mse);
         stats[5] = 0.f; stats[6] = 0.f; stats[7] = 0.f;
+        if (ring) {                                  // engine: publish into the per-step ring (slot from the cursor)
+            float *r = ring + (size_t)cur->slot * 8;
+            r[0] = loss * loss_scale; r[1] = l1; r[2] = mse; r[3] = ss; r[4] = stats[4];
+            r[5] = cur->lr; r[6] = (float)cur->frame; r[7] = (float)cur->step;
+        }
     }
 }
 
@@ -313,7 +319,7 @@ extern "C" size_t orn_loss_ws_bytes(int B, int Ch, int H, int W) { return loss_g
 
 int orn_launch_loss(const float *pred, const float *target, const int *frame_idx, size_t frame_stride, int B, int Ch,
                     int H, int W, int loss_type, float loss_scale, float *stats, float *dpred, float *ws,
-                    hipStream_t st)
+                    hipStream_t st, const OrnStepCur *cur, float *ring)
 {
     ORN_REQUIRE(loss_type == ORN_LOSS_L2 || loss_type == ORN_LOSS_L1 || loss_type == ORN_LOSS_FUSION6,
                 "loss: unsupported loss_type %d", loss_type);
@@ -340,7 +346,7 @@ int orn_launch_loss(const float *pred, const float *target, const int *frame_idx
     hipLaunchKernelGGL(k_loss_grad, dim3(g.tw * g.th, g.planes), dim3(256), 0, st, q);
     ORN_LAUNCH_CHECK("loss_grad");
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, st, q.part_ssim, n_ssim, q.part_l1, g.planes * g.tw * g.th, n,
-                       (double)g.nmap, loss_type, loss_scale, stats);
+                       (double)g.nmap, loss_type, loss_scale, stats, cur, ring);
     ORN_LAUNCH_CHECK("loss_finalize");
     return 0;
 }
@@ -356,7 +362,7 @@ extern "C" int orn_loss_fwd_bwd(const float *pred, const float *target, int B, i
         return ORN_E_WS;
     }
     return orn_launch_loss(pred, target, nullptr, 0, B, Ch, H, W, loss_type, loss_scale, stats, dpred, (float *)ws,
-                           (hipStream_t)stream);
+                           (hipStream_t)stream, nullptr, nullptr);
 }
 
 // ================================================================================================

@@ -84,7 +84,7 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize('half', ['bf16', 'fp16'])
-@pytest.mark.parametrize('fc,strides,lw,bt', [('3_4_96', [2, 2], 96, 'ERB'), ('2_3_26', [5, 2, 2], 96, 'ERB'),
+@pytest.mark.parametrize('fc,strides,lw,bt', [('3_4_96', [2, 2], 96, 'ERB'), ('2_3_26', [5, 2, 2], 96, 'ERB'), ('2_3_48', [5, 3, 2], 96, 'ERB'),
                                                ('3_4_96', [2, 2, 2], 96, 'NeRV_vanilla')])
 def test_bf16_engine_vs_fp32_engine(orn, fc, strides, lw, bt, half):
     """One optimiser step of the 16-bit engine (bf16 or IEEE half) vs the fp32 engine (itself pinned to the
@@ -118,14 +118,17 @@ def test_bf16_engine_vs_fp32_engine(orn, fc, strides, lw, bt, half):
     assert worst[0] < (6e-3 if tight else 3e-2), worst
 
 
-@pytest.mark.parametrize('half', ['bf16', 'fp16'])
-def test_bf16_engine_720p_decode_and_step(orn, half):
-    """BASELINE config 2 on the bf16 path: decode agrees with the fp32 path (PSNR between the two
-    decoders > 50 dB) and a training step runs with finite loss and gradients close to fp32."""
+@pytest.mark.parametrize('half,cfg', [('bf16', '720p'), ('fp16', '720p'), ('fp16', '1080p')])
+def test_bf16_engine_720p_decode_and_step(orn, half, cfg):
+    """BASELINE config 2 (720p, 9_16_26, strides 5 2 2 2 2) and config 3 (1080p, 9_16_48, strides 5 3 2 2 2: stride-3
+    block, 135x240 / 270x480 / 540x960 conv inputs that are not multiples of the pixel tile) on the 16-bit path: decode
+    agrees with the fp32 path (PSNR between the two decoders > 50 / 65 dB) and a training step runs with finite loss
+    and gradients close to fp32."""
     import bench
     outs = {}
+    kw = dict(fc_hw_dim='9_16_48', strides=[5, 3, 2, 2, 2], hw=(1080, 1920), frames=8) if cfg == '1080p' else {}
     for prec in ('fp32', half):
-        eng = bench.make_engine(seed=1234, precision=prec)
+        eng = bench.make_engine(seed=1234, precision=prec, **kw)
         eng.set_schedule([(7, 1, 0.0)])
         eng.run(1, graph=True)
         torch.cuda.synchronize()
