@@ -75,7 +75,7 @@ def schedule(n_steps, start_step=0):
 
 def conv_roofline(eng, precision, iters=10):
     """Dominant kernel = the implicit-GEMM 3x3 conv forward.  fp32: k_conv3x3_f32<EPI_PS_SILU>, 5 launches
-    per step (L0..L4); bf16: k_conv_nhwc_bf16<4,2,2,2,EPI_B_FWD>, 3 launches per step (L2..L4).  Times
+    per step (L0..L4); 16-bit: k_conv_nhwc_bf16<4,2,2,2,EPI_B_FWD>, one launch per fast layer (720p: L1..L4).  Times
     every launch of that kernel symbol in a step with HIP events on the launch stream and returns
     (algorithmic flops per launch, avg launch duration [s]) averaged over those launches, so that it
     agrees with rocprofv3's per-kernel average for the symbol."""
@@ -86,18 +86,28 @@ def conv_roofline(eng, precision, iters=10):
     dev = eng.device
     tot_t, tot_f, n = 0.0, 0.0, 0
     per_layer = []
+    # the engine's rule (orn_engine.hip first_fast_layer): trailing layers with C == 96 and O % 128 == 0, plus one
+    # narrower layer below them run zero-padded to 96 channels
+    ff = len(geo)
+    while ff > 0 and geo[ff - 1]['C'] == 96 and geo[ff - 1]['O'] % 128 == 0:
+        ff -= 1
+    if 0 < ff < len(geo) and geo[ff - 1]['C'] < 96 and geo[ff - 1]['O'] % 128 == 0:
+        ff -= 1
     for li, L in enumerate(geo):
         C, O, s, H, W = L['C'], L['O'], L['s'], L['H'], L['W']
+        Creal = C
         st = _lib.stream()
         if precision in ('bf16', 'fp16'):
-            if C != 96:
+            if li < ff:
                 continue
+            C = 96                                        # channels per pixel in HBM (zeros above Creal)
             Cn = O // (s * s)
             hdt = torch.bfloat16 if precision == 'bf16' else torch.float16
             fwd = lib.orn_conv_nhwc_bf16_fwd if precision == 'bf16' else lib.orn_conv_nhwc_f16_fwd
             xpad = torch.zeros(H + 2, W + 2, C, device=dev, dtype=hdt)
-            xpad[1:-1, 1:-1] = torch.randn(H, W, C, device=dev).to(hdt)
-            wb = (torch.randn(9, O, C, device=dev) * (1.0 / (9 * C) ** 0.5)).to(hdt)
+            xpad[1:-1, 1:-1, :Creal] = torch.randn(H, W, Creal, device=dev).to(hdt)
+            wb = torch.zeros(9, O, C, device=dev, dtype=hdt)
+            wb[:, :, :Creal] = (torch.randn(9, O, Creal, device=dev) * (1.0 / (9 * Creal) ** 0.5)).to(hdt)
             bp = torch.zeros(O, device=dev)
             z = torch.empty(H * s, W * s, Cn, device=dev, dtype=hdt)
             apad = torch.zeros(H * s + 2, W * s + 2, Cn, device=dev, dtype=hdt) if li + 1 < len(geo) else None
@@ -126,7 +136,7 @@ def conv_roofline(eng, precision, iters=10):
         e1.record()
         e1.synchronize()
         dt = e0.elapsed_time(e1) / 1e3 / iters
-        fl = 2.0 * C * 9 * O * H * W
+        fl = 2.0 * Creal * 9 * O * H * W                 # algorithmic: the real input channels only
         per_layer.append(dict(layer=li, ms=dt * 1e3, tflops=fl / dt / 1e12))
         tot_t += dt
         tot_f += fl
@@ -225,7 +235,7 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                          'traffic': traffic,
                          'kernel': ('k_conv3x3_f32<EPI_PS_SILU> (5 launches/step, L0..L4)' if args.precision == 'fp32'
-                                    else f'orn_{"bf16" if args.precision == "bf16" else "f16"}::k_conv_nhwc_bf16<4,2,2,2,EPI_B_FWD> (3 launches/step, L2..L4)'),
+                                    else f'orn_{"bf16" if args.precision == "bf16" else "f16"}::k_conv_nhwc_bf16<4,2,2,2,EPI_B_FWD> ({len(per_layer)} launches/step, L{per_layer[0]["layer"]}..L{per_layer[-1]["layer"]})'),
                          'flops_per_launch': fl, 'avg_launch_ms': avg_dt * 1e3, 'per_layer': per_layer},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -408,6 +408,34 @@ int orn_dgrad_f32_slabs(int H, int W, int O)
     return (orn_cdiv(W, CB_TW) * orn_cdiv(H, CB_TH) < 128 && O / CB_CK > 1) ? O / CB_CK : 1;
 }
 
+// Small images (too few pixel tiles to fill the chip): the dgrad runs split over the input chunks into fp32 partial
+// slabs [Q][H][W][96]; this pass sums them (fixed order), applies SiLU'(z_prev) and scatters into the previous layer's
+// dypad -- what the EPI_B_DGRAD epilogue does in one go on large images.
+__global__ void __launch_bounds__(256) k_dgrad_finish(const float *__restrict__ slabs, int Q, const h16 *__restrict__ zprev, int H, int W,
+                                                     int sp, h16 *__restrict__ dyprev)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // (pixel, 8-channel group)
+    const size_t n = (size_t)H * W * 12;
+    if (idx >= n) return;
+    const size_t pix = idx / 12;
+    const int c8 = (int)(idx - pix * 12) * 8;
+    const int gh = (int)(pix / W), gw = (int)(pix - (size_t)gh * W);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < Q; ++q) {
+        const float *src = slabs + ((size_t)q * H * W + pix) * 96 + c8;
+        const float4 a = *reinterpret_cast<const float4 *>(src), b = *reinterpret_cast<const float4 *>(src + 4);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+    const h16x8 zz = *reinterpret_cast<const h16x8 *>(zprev + pix * 96 + c8);
+    h16x8 o8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o8[e] = (h16)(v[e] * orn_silu_grad((float)zz[e]));
+    const int ph = gh / sp, pw = gw / sp, sub = (gh - ph * sp) * sp + (gw - pw * sp);
+    *reinterpret_cast<h16x8 *>(dyprev + ((size_t)(ph + 1) * (W / sp + 2) + (pw + 1)) * (96 * sp * sp) + sub * 96 + c8) = o8;
+}
+
+// dx_f32 alone: fp32 output slabs (layer below is fp32).  zprev/dyprev alone: fused epilogue.  Both: dx_f32 is scratch for
+// orn_dgrad_f32_slabs(H, W, O) partial slabs and the result is finished into dyprev (small images).
 int orn_launch_conv_bf16_dgrad(const h16 *dypad, const h16 *wd, int H, int W, int O, int C, const h16 *zprev,
                                h16 *dyprev, int sp, float *dx_f32, hipStream_t st)
 {
@@ -420,7 +448,13 @@ int orn_launch_conv_bf16_dgrad(const h16 *dypad, const h16 *wd, int H, int W, in
     p.zprev = zprev; p.dyprev = dyprev; p.sp = sp; p.dx_f32 = dx_f32;
     if (dx_f32) {
         p.qsplit = (p.tiles_w * p.tiles_h < 128 && O / CB_CK > 1) ? 1 : 0;   // few pixel tiles: one work-group per input chunk
-        return launch_conv_cfg<8, 1, 1, 3, EPI_B_DGRAD_F32>(p, 1, st);
+        if (!zprev) return launch_conv_cfg<8, 1, 1, 3, EPI_B_DGRAD_F32>(p, 1, st);
+        ORN_REQUIRE(dyprev && sp >= 1 && H % sp == 0 && W % sp == 0 && p.qsplit, "conv_bf16_dgrad: bad split-epilogue arguments");
+        p.zprev = nullptr; p.dyprev = nullptr;
+        ORN_TRY((launch_conv_cfg<8, 1, 1, 3, EPI_B_DGRAD_F32>(p, 1, st)));
+        hipLaunchKernelGGL(k_dgrad_finish, dim3(orn_cdiv((long)H * W * 12, 256)), dim3(256), 0, st, dx_f32, O / CB_CK, zprev, H, W, sp, dyprev);
+        ORN_LAUNCH_CHECK("dgrad_finish");
+        return 0;
     }
     ORN_REQUIRE(zprev && dyprev && sp >= 1 && H % sp == 0 && W % sp == 0, "conv_bf16_dgrad: bad epilogue arguments");
     return launch_conv_cfg<8, 1, 1, 3, EPI_B_DGRAD>(p, 1, st);

@@ -137,6 +137,8 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
             const OrnHalfOps *ops = orn_half_ops_bf16();     // sizes do not depend on the element type
             if (i == ff) dxn = take((size_t)l.H * l.W * ORN_FAST_C * ops->dgrad_f32_slabs(l.H, l.W, l.O));
             s1 = al(ops->wgrad_ws_floats(l.H, l.W, l.O));
+            const size_t sd = (size_t)l.H * l.W * ORN_FAST_C * ops->dgrad_f32_slabs(l.H, l.W, l.O);
+            if (ops->dgrad_f32_slabs(l.H, l.W, l.O) > 1 && sd > s1) s1 = sd;
         }
         if (d->erb) { const size_t s2 = orn_erb_merge_bwd_ws_bytes(l.C, l.O) / 4; if (s2 > s1) s1 = s2; }
         if (s1 > scratch) scratch = s1;
@@ -344,8 +346,10 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         if (i >= ff) {
             ORN_TRY(e->ops->wgrad(b.xpad, b.dypad, l.H, l.W, l.C, l.O, l.s, 1.0f / e->gs, e->scratch, G + l.w3x3, G + l.b3x3, st));
             if (i > ff) {
+                // few pixel tiles: input-chunk split through fp32 partial slabs in the scratch, finished into dypad
+                float *part = e->ops->dgrad_f32_slabs(l.H, l.W, l.O) > 1 ? e->scratch : nullptr;
                 ORN_TRY(e->ops->conv_dgrad(b.dypad, b.wd, l.H, l.W, l.O, l.C, e->L[i - 1].zb, e->L[i - 1].dypad, d.layer[i - 1].s,
-                                           nullptr, st));
+                                           part, st));
             } else {
                 ORN_TRY(e->ops->conv_dgrad(b.dypad, b.wd, l.H, l.W, l.O, ORN_FAST_C, nullptr, nullptr, 1, e->dxn, st));
                 ORN_TRY(e->ops->to_nchw_f32(e->dxn, l.C, ORN_FAST_C, l.H, l.W, e->ops->dgrad_f32_slabs(l.H, l.W, l.O), 1.0f / e->gs, dx,
