@@ -51,44 +51,40 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, int bx, int by, int bz
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    // per-thread element coordinates inside a 64x64 tile (16 A + 16 B elements), loop invariant
+    // Per-thread element coordinates inside a 64x64 tile (16 A + 16 B elements): one coordinate is the thread's own
+    // (t & 63, along the operand's contiguous dimension), the other steps by 4 with i.  Loads are UNCONDITIONAL
+    // (exec-mask branches around 32 loads per chunk cost more than the chunk's MFMAs): edge rows / columns are clamped
+    // onto the last valid one (loaded for nothing, never stored), the K tail is clamped for the address and replaced
+    // by +0.0f (fma(0, 0, acc) == acc keeps the chain exact).  24-bit multiplies: operands are weight-sized.
     constexpr int NE = GT * GK / 256;
     float ra[NE], rb[NE];
-    long aoff[NE], boff[NE];
-    int alds[NE], blds[NE];
-    bool aok[NE], bok[NE];
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        int kk, m;
-        if (p.a_kfast) { kk = t & 63; m = (t >> 6) + 4 * i; }
-        else           { m = t & 63;  kk = (t >> 6) + 4 * i; }
-        aoff[i] = (long)(m0 + m) * p.sam + (long)kk * p.sak;
-        alds[i] = m * GLDA + kk;
-        aok[i] = (m0 + m) < p.M;
-        int kb, n;
-        if (p.b_nfast) { n = t & 63;  kb = (t >> 6) + 4 * i; }
-        else           { kb = t & 63; n = (t >> 6) + 4 * i; }
-        boff[i] = (long)kb * p.sbk + (long)(n0 + n) * p.sbn;
-        blds[i] = kb * GLDB + n;
-        bok[i] = (n0 + n) < p.N;
-    }
-    // kk / kb of element i (needed for the K bound)
-    auto kk_of = [&](int i) { return p.a_kfast ? (t & 63) : (t >> 6) + 4 * i; };
-    auto kb_of = [&](int i) { return p.b_nfast ? (t >> 6) + 4 * i : (t & 63); };
+    const int tf = t & 63, tv = t >> 6;
+    const int M = p.M, N = p.N, K = p.K;
+    const int sam = (int)p.sam, sak = (int)p.sak, sbk = (int)p.sbk, sbn = (int)p.sbn;
+    const bool akf = p.a_kfast, bnf = p.b_nfast;
+    auto gload1 = [&](int k0, int i) {
+        {
+            const int v = tv + 4 * i;
+            const int am = akf ? v : tf, ak = k0 + (akf ? tf : v);
+            const int bn = bnf ? tf : v, bk = k0 + (bnf ? v : tf);
+            const float va = A[__mul24(min(m0 + am, M - 1), sam) + __mul24(min(ak, K - 1), sak)];
+            const float vb = B[__mul24(min(bk, K - 1), sbk) + __mul24(min(n0 + bn, N - 1), sbn)];
+            ra[i] = va;                         // the K-tail zeroing happens at the LDS store: consuming the value here
+            rb[i] = vb;                         // would put the load wait in front of this chunk's MFMAs
+        }
+    };
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            ra[i] = (aok[i] && k0 + kk_of(i) < p.K) ? A[aoff[i] + (long)k0 * p.sak] : 0.f;
-            rb[i] = (bok[i] && k0 + kb_of(i) < p.K) ? B[boff[i] + (long)k0 * p.sbk] : 0.f;
-        }
+        for (int i = 0; i < NE; ++i) gload1(k0, i);
     };
     gload(0);
     for (int k0 = 0; k0 < p.K; k0 += GK) {
         __syncthreads();                       // everyone is done reading the previous chunk
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
-            (&As[0][0])[alds[i]] = ra[i];
-            (&Bs[0][0])[blds[i]] = rb[i];
+            const int v = tv + 4 * i;
+            As[akf ? v : tf][akf ? tf : v] = (k0 + (akf ? tf : v) < K) ? ra[i] : 0.f;
+            Bs[bnf ? v : tf][bnf ? tf : v] = (k0 + (bnf ? v : tf) < K) ? rb[i] : 0.f;
         }
         __syncthreads();
         if (k0 + GK < p.K) gload(k0 + GK);     // next chunk's loads fly under this chunk's 32 MFMAs
@@ -139,31 +135,20 @@ __device__ __forceinline__ void gemm_body_h16(const GemmP &p, int bx, int by, in
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     constexpr int NE = GT * HK / 256;
     float ra[NE], rb[NE];
-    long aoff[NE], boff[NE];
-    int alds[NE], blds[NE], akk[NE], bkk[NE];
-    bool aok[NE], bok[NE];
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        int kk, m;
-        if (p.a_kfast) { kk = t & 63; m = (t >> 6) + 4 * i; }
-        else           { m = t & 63;  kk = (t >> 6) + 4 * i; }
-        aoff[i] = (long)(m0 + m) * p.sam + (long)kk * p.sak;
-        alds[i] = m * HROW + kk * 2;
-        akk[i] = kk;
-        aok[i] = (m0 + m) < p.M;
-        int kb, n;
-        if (p.b_nfast) { n = t & 63;  kb = (t >> 6) + 4 * i; }
-        else           { kb = t & 63; n = (t >> 6) + 4 * i; }
-        boff[i] = (long)kb * p.sbk + (long)(n0 + n) * p.sbn;
-        blds[i] = n * HROW + kb * 2;
-        bkk[i] = kb;
-        bok[i] = (n0 + n) < p.N;
-    }
-    auto gload = [&](int k0) {
+    const int tf = t & 63, tv = t >> 6;
+    const int M = p.M, N = p.N, K = p.K;
+    const int sam = (int)p.sam, sak = (int)p.sak, sbk = (int)p.sbk, sbn = (int)p.sbn;
+    const bool akf = p.a_kfast, bnf = p.b_nfast;
+    auto gload = [&](int k0) {                  // unconditional clamped loads, see gemm_body
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
-            ra[i] = (aok[i] && k0 + akk[i] < p.K) ? A[aoff[i] + (long)k0 * p.sak] : 0.f;
-            rb[i] = (bok[i] && k0 + bkk[i] < p.K) ? B[boff[i] + (long)k0 * p.sbk] : 0.f;
+            const int v = tv + 4 * i;
+            const int am = akf ? v : tf, ak = k0 + (akf ? tf : v);
+            const int bn = bnf ? tf : v, bk = k0 + (bnf ? v : tf);
+            const float va = A[__mul24(min(m0 + am, M - 1), sam) + __mul24(min(ak, K - 1), sak)];
+            const float vb = B[__mul24(min(bk, K - 1), sbk) + __mul24(min(n0 + bn, N - 1), sbn)];
+            ra[i] = va;                         // the K-tail zeroing happens at the LDS store: consuming the value here
+            rb[i] = vb;                         // would put the load wait in front of this chunk's MFMAs
         }
     };
     gload(0);
@@ -171,8 +156,10 @@ __device__ __forceinline__ void gemm_body_h16(const GemmP &p, int bx, int by, in
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
-            *reinterpret_cast<_Float16 *>(Ah + alds[i]) = (_Float16)(ra[i] * p.sa);
-            *reinterpret_cast<_Float16 *>(Bh + blds[i]) = (_Float16)(rb[i] * p.sb);
+            const int v = tv + 4 * i;
+            const float xa = (k0 + (akf ? tf : v) < K) ? ra[i] : 0.f, xb = (k0 + (bnf ? v : tf) < K) ? rb[i] : 0.f;
+            *reinterpret_cast<_Float16 *>(Ah + (akf ? v : tf) * HROW + (akf ? tf : v) * 2) = (_Float16)(xa * p.sa);
+            *reinterpret_cast<_Float16 *>(Bh + (bnf ? tf : v) * HROW + (bnf ? v : tf) * 2) = (_Float16)(xb * p.sb);
         }
         __syncthreads();
         if (k0 + HK < p.K) gload(k0 + HK);
