@@ -171,6 +171,31 @@ __global__ void k_linear_silu_bwd_w(const float *__restrict__ x, const int *__re
     }
 }
 
+// B == 1 variant whose upstream gradient arrives as `nslab` partial rows (k_linear_bwd_x_partial): the block sums its
+// column in fixed order itself, so no standalone reduction launch is needed.
+__global__ void __launch_bounds__(128)
+k_linear_silu_bwd_w_slabs(const float *__restrict__ x, const int *__restrict__ row_idx, size_t row_stride,
+                          const float *__restrict__ pre, const float *__restrict__ dy_slabs, int nslab, int K, int N,
+                          float *__restrict__ dpre, float *__restrict__ dw, float *__restrict__ db)
+{
+    __shared__ float sred[16];
+    __shared__ float sd;
+    const int o = blockIdx.x;
+    if (row_idx) x += (size_t)(*row_idx) * row_stride;
+    float v = 0.f;
+    for (int r = threadIdx.x; r < nslab; r += blockDim.x) v += dy_slabs[(size_t)r * N + o];
+    const float tot = orn_block_sum(v, sred);
+    if (threadIdx.x == 0) {
+        const float d = tot * orn_silu_grad_exact(pre[o]);
+        sd = d;
+        dpre[o] = d;
+        db[o] = d;
+    }
+    __syncthreads();
+    const float d = sd;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) dw[(size_t)o * K + k] = d * x[k];
+}
+
 // partial[chunk][b][k] = sum_{o in chunk} w[o][k]*dpre[b][o]
 __global__ void k_linear_bwd_x_partial(const float *__restrict__ w, const float *__restrict__ dpre, int B, int K,
                                        int N, int rows_per_chunk, float *__restrict__ partial)
@@ -204,6 +229,12 @@ int orn_launch_stem_bwd(const float *embed, const int *row_idx, size_t row_strid
     hipLaunchKernelGGL(k_linear_bwd_x_partial, dim3(orn_cdiv(Hd, 128), ORN_STEM_CHUNKS), dim3(128), 0, st, w1, dpre2, B,
                        Hd, Nout, rpc, partial);
     ORN_LAUNCH_CHECK("stem_bwd_x");
+    if (B == 1) {
+        hipLaunchKernelGGL(k_linear_silu_bwd_w_slabs, dim3(Hd), dim3(128), 0, st, embed, row_idx, row_stride, pre1, partial,
+                           ORN_STEM_CHUNKS, E, Hd, dpre1, dw0, db0);
+        ORN_LAUNCH_CHECK("stem_bwd_w0");
+        return 0;
+    }
     ORN_TRY(orn_launch_reduce_rows(partial, ORN_STEM_CHUNKS, (size_t)B * Hd, (size_t)B * Hd, dh1, st));
     hipLaunchKernelGGL(k_linear_silu_bwd_w, dim3(Hd), dim3(128), 0, st, embed, row_idx, row_stride, pre1, dh1, B, E, Hd,
                        dpre1, dw0, db0);

@@ -136,9 +136,9 @@ class TrainEngine:
         if h is not None and h.value:
             try:
                 lib().orn_engine_destroy(h)
-            except Exception:
+                self._h = c_void_p()
+            except Exception:          # interpreter shutdown: module globals may already be gone
                 pass
-            self._h = c_void_p()
 
     # ---- data ---------------------------------------------------------------------------------
     def set_video(self, frames: torch.Tensor, embeds: torch.Tensor):

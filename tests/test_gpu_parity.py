@@ -391,6 +391,34 @@ def test_engine_matches_oracle_training(orn, bt, graph):
     assert torch.allclose(img_e, img_m, rtol=0, atol=1e-6)
 
 
+def test_720p_gradients_vs_oracle(orn):
+    """BASELINE config 2 at FULL size: loss, PSNR and every one of the 51 gradient tensors of one Fusion6 training
+    step of the fp32 engine against the CPU oracle's autograd on the same seeded model and frame (lr 0, so the
+    parameters stay put).  Tolerance: relative L2 <= 2e-3 per tensor (fp32 accumulation order differs: MFMA split-K
+    vs ATen), loss within 5e-5 relative (fp32 SSIM means over 2.7 M pixels on both sides)."""
+    from oracle import cpu_ref
+    torch.manual_seed(1)
+    gen = _make_720p(orn)
+    sd = {k: v.detach().clone() for k, v in gen.state_dict().items()}
+    frames = cpu_ref.synthetic_video(2, 720, 1280, seed=11)
+    embeds = cpu_ref.positional_encoding(torch.tensor([0.0, 0.5]), 1.25, 40)
+    eng = orn.engine.TrainEngine(gen, loss_type='Fusion6', beta=0.5, precision='fp32')
+    eng.set_video(frames, embeds)
+    eng.set_schedule([(1, 1, 0.0)])
+    eng.run(1, graph=False)
+    torch.cuda.synchronize()
+    st = eng.stats(1)[0].numpy()
+    grads = {k: eng.grads[off:off + n].clone().cpu() for k, (off, n) in eng.layout.items()}
+    am = {k: torch.zeros_like(v) for k, v in sd.items()}
+    av = {k: torch.zeros_like(v) for k, v in sd.items()}
+    loss, psnr, ref = cpu_ref.train_step(sd, am, av, 1, 0.0, embeds[1:2], frames[1:2], '9_16_26', [5, 2, 2, 2, 2], 'ERB', 'Fusion6', 0.5)
+    assert abs(st[0] - loss.item()) <= 5e-5 * abs(loss.item()), (st[0], loss.item())
+    assert abs(st[4] - psnr.item()) < 1e-3
+    assert len(ref) == 51
+    rel = sorted(((float((grads[k] - ref[k].flatten()).norm() / (ref[k].norm() + 1e-30)), k) for k in ref), reverse=True)
+    assert rel[0][0] < 2e-3, rel[:8]
+
+
 def test_deploy_checkpoint_round_trip(orn, golden, tmp_path):
     """N1: a reference *_deploy.pth decodes frame-for-frame; our deploy export of a trained ERB model
     equals the reference's switch_to_deploy result and decodes identically through the engine's decode path."""

@@ -23,6 +23,8 @@ def run(precision, epochs, frames, seed, noise):
         eng.run(n)
         st = eng.stats(n)
         hist.append(float(st[:, 4].mean()))
+        if ep % 20 == 19:
+            print(f'# {precision} epoch {ep + 1}/{epochs} train PSNR {hist[-1]:.3f} dB  {time.time() - t0:.0f} s', file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     dt = time.time() - t0
     ps = []
