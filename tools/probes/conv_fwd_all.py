@@ -1,7 +1,8 @@
-"""Launch the dominant kernel (16-bit conv forward) once per fast layer of BASELINE config 2 (L2, L3, L4), after a
+"""Launch the dominant kernel (16-bit conv forward) once per fast layer of BASELINE config 2 (L1 zero-padded to 96 channels, L2, L3, L4), after a
 warm-up, for rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE)."""
 import sys, torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from ctypes import c_void_p
 import orn_amd
 from orn_amd import _lib
@@ -12,11 +13,12 @@ fwd = lib.orn_conv_nhwc_f16_fwd if prec == 'fp16' else lib.orn_conv_nhwc_bf16_fw
 st = _lib.stream()
 keep = []
 for rep in range(2):
-    for (H, W, last) in ((90, 160, False), (180, 320, False), (360, 640, True)):
+    for (H, W, Cr, last) in ((45, 80, 26, False), (90, 160, 96, False), (180, 320, 96, False), (360, 640, 96, True)):
         C, O, s = 96, 384, 2
         xpad = torch.zeros(H + 2, W + 2, C, device='cuda', dtype=hdt)
-        xpad[1:-1, 1:-1] = torch.randn(H, W, C, device='cuda').to(hdt)
-        wb = (torch.randn(9, O, C, device='cuda') * 0.034).to(hdt)
+        xpad[1:-1, 1:-1, :Cr] = torch.randn(H, W, Cr, device='cuda').to(hdt)
+        wb = torch.zeros(9, O, C, device='cuda', dtype=hdt)
+        wb[:, :, :Cr] = (torch.randn(9, O, Cr, device='cuda') * 0.034).to(hdt)
         bp = torch.zeros(O, device='cuda')
         z = torch.empty(H * s, W * s, 96, device='cuda', dtype=hdt)
         apad = None if last else torch.zeros(H * s + 2, W * s + 2, 96, device='cuda', dtype=hdt)
