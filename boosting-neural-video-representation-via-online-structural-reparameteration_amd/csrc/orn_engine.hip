@@ -37,13 +37,16 @@ struct orn_engine {
     int merge_tiles[4];
     int ff;                          // first layer on the bf16 fast path (== n_layers: none)
     float *dxn;                      // fp32 NHWC dgrad output of layer ff (converted to NCHW for the fp32 part)
-    // graph cache (one captured train step)
-    hipGraph_t graph;
-    hipGraphExec_t graph_exec;
+    // graph cache: one captured train step, and ORN_GRAPH_UNROLL steps back to back (the schedule is device-side, so
+    // a longer graph is the same nodes repeated; it amortises the ~8 us gap between graph launches)
+    hipGraph_t graph, graph_u;
+    hipGraphExec_t graph_exec, graph_exec_u;
     const void *g_frames, *g_embeds, *g_sched, *g_cursor, *g_stats;
     int g_slots;
     hipStream_t g_stream;
 };
+
+#define ORN_GRAPH_UNROLL 4
 
 static inline size_t al(size_t floats) { return orn_align(floats * 4) / 4; }
 
@@ -187,7 +190,7 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
     e->d = *d;
     e->params = params; e->grads = grads; e->m = adam_m; e->v = adam_v;
     e->ws = (float *)ws;
-    e->graph = nullptr; e->graph_exec = nullptr;
+    e->graph = nullptr; e->graph_exec = nullptr; e->graph_u = nullptr; e->graph_exec_u = nullptr;
     e->ops = (d->precision == 2) ? orn_half_ops_f16() : orn_half_ops_bf16();
     e->gs = (d->precision == 2) ? 1048576.0f : 1.0f;
     layout(d, e);
@@ -228,6 +231,8 @@ extern "C" void orn_engine_destroy(orn_engine *e)
     if (!e) return;
     if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
     if (e->graph) (void)hipGraphDestroy(e->graph);
+    if (e->graph_exec_u) (void)hipGraphExecDestroy(e->graph_exec_u);
+    if (e->graph_u) (void)hipGraphDestroy(e->graph_u);
     delete e;
 }
 
@@ -400,20 +405,31 @@ extern "C" int orn_engine_train_steps_graph(orn_engine *e, const float *frames, 
     if (!same) {
         if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
         if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
-        hipError_t rc = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-        if (rc != hipSuccess) { orn_set_error("graph: BeginCapture failed: %s", hipGetErrorString(rc)); return (int)rc; }
-        const int trc = train_step(e, frames, embeds, sched, cursor, stats_out, n_slots, st);
-        rc = hipStreamEndCapture(st, &e->graph);
-        if (trc != 0) { if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; } return trc; }
-        if (rc != hipSuccess) { orn_set_error("graph: EndCapture failed: %s", hipGetErrorString(rc)); return (int)rc; }
-        rc = hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0);
-        if (rc != hipSuccess) { orn_set_error("graph: Instantiate failed: %s", hipGetErrorString(rc)); return (int)rc; }
+        if (e->graph_exec_u) { (void)hipGraphExecDestroy(e->graph_exec_u); e->graph_exec_u = nullptr; }
+        if (e->graph_u) { (void)hipGraphDestroy(e->graph_u); e->graph_u = nullptr; }
+        for (int pass = 0; pass < 2; ++pass) {
+            const int reps = pass == 0 ? 1 : ORN_GRAPH_UNROLL;
+            hipGraph_t *g = pass == 0 ? &e->graph : &e->graph_u;
+            hipGraphExec_t *ge = pass == 0 ? &e->graph_exec : &e->graph_exec_u;
+            hipError_t rc = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+            if (rc != hipSuccess) { orn_set_error("graph: BeginCapture failed: %s", hipGetErrorString(rc)); return (int)rc; }
+            int trc = 0;
+            for (int r = 0; r < reps && trc == 0; ++r) trc = train_step(e, frames, embeds, sched, cursor, stats_out, n_slots, st);
+            rc = hipStreamEndCapture(st, g);
+            if (trc != 0) { if (*g) { (void)hipGraphDestroy(*g); *g = nullptr; } return trc; }
+            if (rc != hipSuccess) { orn_set_error("graph: EndCapture failed: %s", hipGetErrorString(rc)); return (int)rc; }
+            rc = hipGraphInstantiate(ge, *g, nullptr, nullptr, 0);
+            if (rc != hipSuccess) { orn_set_error("graph: Instantiate failed: %s", hipGetErrorString(rc)); return (int)rc; }
+        }
         e->g_frames = frames; e->g_embeds = embeds; e->g_sched = sched; e->g_cursor = cursor; e->g_stats = stats_out;
         e->g_slots = n_slots; e->g_stream = st;
     }
-    for (int i = 0; i < n_steps; ++i) {
-        hipError_t rc = hipGraphLaunch(e->graph_exec, st);
+    int left = n_steps;
+    while (left > 0) {
+        const bool big = left >= ORN_GRAPH_UNROLL;
+        hipError_t rc = hipGraphLaunch(big ? e->graph_exec_u : e->graph_exec, st);
         if (rc != hipSuccess) { orn_set_error("graph: Launch failed: %s", hipGetErrorString(rc)); return (int)rc; }
+        left -= big ? ORN_GRAPH_UNROLL : 1;
     }
     return 0;
 }
