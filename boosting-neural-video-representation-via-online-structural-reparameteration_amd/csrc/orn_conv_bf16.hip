@@ -662,6 +662,9 @@ int orn_wgrad_bf16_split(int H, int W, int O)
     const int n_ktiles = orn_cdiv(H, WB_TH) * orn_cdiv(W, WB_TW);
     const int per = 3 * (O / WB_BO);
     int S = (512 / per) / 8 * 8;
+    // measured at the 720p shapes: below ~2000 K tiles a full wave of work-groups makes the slab write + re-read cost
+    // more than the idle CUs do (L3, 900 tiles: 40 slabs beat 56 by 17 us per step)
+    if (n_ktiles < 2000 && S > 40) S = 40;
     const int by_work = (n_ktiles / 8) / 8 * 8;
     if (S > by_work) S = by_work;
     if (S < 8) S = 8;
