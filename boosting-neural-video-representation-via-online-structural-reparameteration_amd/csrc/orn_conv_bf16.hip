@@ -1045,7 +1045,7 @@ int orn_launch_head_fwd_bf16(const h16 *z, const float *w, const float *b, int C
 {
     ORN_REQUIRE(C % 32 == 0 && C <= HB_MAXC, "head_bf16: unsupported C=%d", C);
     int blocks = orn_cdiv((long)HW, 64);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 8192) blocks = 8192;           // measured: 8192 beats 2048 by ~7 us at 720p
     hipLaunchKernelGGL(k_head_fwd_nhwc_bf16, dim3(blocks), dim3(256), 0, st, z, w, b, C, HW, sigmoid, out);
     ORN_LAUNCH_CHECK("head_fwd_bf16");
     return 0;
