@@ -73,75 +73,39 @@ def schedule(n_steps, start_step=0):
     return out
 
 
-def conv_roofline(eng, precision, iters=10):
-    """Dominant kernel = the implicit-GEMM 3x3 conv forward.  fp32: k_conv3x3_f32<EPI_PS_SILU>, 5 launches
-    per step (L0..L4); 16-bit: k_conv_nhwc_bf16<4,2,2,2,EPI_B_FWD>, one launch per fast layer (720p: L1..L4).  Times
-    every launch of that kernel symbol in a step with HIP events on the launch stream and returns
-    (algorithmic flops per launch, avg launch duration [s]) averaged over those launches, so that it
-    agrees with rocprofv3's per-kernel average for the symbol."""
-    from orn_amd import _lib
-    from ctypes import c_void_p
-    lib = _lib.lib()
+def conv_roofline(eng, precision, iters=20):
+    """Dominant kernel = the implicit-GEMM 3x3 conv forward.  fp32: k_conv3x3_f32<EPI_PS_SILU>, one launch per layer
+    (L0..L4); 16-bit: k_conv_nhwc_bf16<4,2,2,2,EPI_B_FWD>, one launch per fast layer (720p: L1..L4; L0 stays on the
+    fp32 kernel and is not part of this symbol).  Durations are measured LIVE inside real training steps: the engine
+    runs `iters` eager steps with HIP events bracketing every layer's forward conv launch on the launch stream
+    (orn_engine_profile_step), so clocks, caches and operands are those of the step -- the same launches rocprofv3
+    averages for the symbol.  Returns (algorithmic flops per launch, avg launch duration [s], per-layer list)."""
     geo = layer_geo()
-    dev = eng.device
-    tot_t, tot_f, n = 0.0, 0.0, 0
-    per_layer = []
-    # the engine's rule (orn_engine.hip first_fast_layer): trailing layers with C == 96 and O % 128 == 0, plus one
-    # narrower layer below them run zero-padded to 96 channels
-    ff = len(geo)
-    while ff > 0 and geo[ff - 1]['C'] == 96 and geo[ff - 1]['O'] % 128 == 0:
-        ff -= 1
-    if 0 < ff < len(geo) and geo[ff - 1]['C'] < 96 and geo[ff - 1]['O'] % 128 == 0:
-        ff -= 1
+    ff = 0
+    if precision in ('bf16', 'fp16'):
+        # the engine's rule (orn_engine.hip first_fast_layer): trailing layers with C == 96 and O % 128 == 0, plus one
+        # narrower layer below them run zero-padded to 96 channels
+        ff = len(geo)
+        while ff > 0 and geo[ff - 1]['C'] == 96 and geo[ff - 1]['O'] % 128 == 0:
+            ff -= 1
+        if 0 < ff < len(geo) and geo[ff - 1]['C'] < 96 and geo[ff - 1]['O'] % 128 == 0:
+            ff -= 1
+    eng.set_schedule(schedule(iters + 2))
+    acc = [0.0] * len(geo)
+    for k in range(iters + 2):
+        ms = eng.profile_step()
+        if k >= 2:
+            acc = [a + m for a, m in zip(acc, ms)]
+    per_layer, tot_t, tot_f, n = [], 0.0, 0.0, 0
     for li, L in enumerate(geo):
-        C, O, s, H, W = L['C'], L['O'], L['s'], L['H'], L['W']
-        Creal = C
-        st = _lib.stream()
-        if precision in ('bf16', 'fp16'):
-            if li < ff:
-                continue
-            C = 96                                        # channels per pixel in HBM (zeros above Creal)
-            Cn = O // (s * s)
-            hdt = torch.bfloat16 if precision == 'bf16' else torch.float16
-            fwd = lib.orn_conv_nhwc_bf16_fwd if precision == 'bf16' else lib.orn_conv_nhwc_f16_fwd
-            xpad = torch.zeros(H + 2, W + 2, C, device=dev, dtype=hdt)
-            xpad[1:-1, 1:-1, :Creal] = torch.randn(H, W, Creal, device=dev).to(hdt)
-            wb = torch.zeros(9, O, C, device=dev, dtype=hdt)
-            wb[:, :, :Creal] = (torch.randn(9, O, Creal, device=dev) * (1.0 / (9 * Creal) ** 0.5)).to(hdt)
-            bp = torch.zeros(O, device=dev)
-            z = torch.empty(H * s, W * s, Cn, device=dev, dtype=hdt)
-            apad = torch.zeros(H * s + 2, W * s + 2, Cn, device=dev, dtype=hdt) if li + 1 < len(geo) else None
-            keep = (xpad, wb, bp, z, apad)
-
-            def run():
-                _lib.check(fwd(c_void_p(xpad.data_ptr()), c_void_p(wb.data_ptr()), _lib.ptr(bp), H, W, C, O, s,
-                                                      c_void_p(z.data_ptr()), c_void_p(apad.data_ptr()) if apad is not None else None, st))
-        else:
-            x = torch.randn(1, C, H, W, device=dev)
-            wf = torch.randn(O, C, 3, 3, device=dev) * (1.0 / (9 * C) ** 0.5)
-            bf = torch.zeros(O, device=dev)
-            z = torch.empty(1, O // (s * s), H * s, W * s, device=dev)
-            a = torch.empty_like(z)
-            keep = (x, wf, bf, z, a)
-
-            def run():
-                _lib.check(lib.orn_conv3x3_ps_silu_fwd(_lib.ptr(x), _lib.ptr(wf), _lib.ptr(bf), 1, C, O, H, W, s, _lib.ptr(z),
-                                                       _lib.ptr(a), st))
-        for _ in range(2):
-            run()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            run()
-        e1.record()
-        e1.synchronize()
-        dt = e0.elapsed_time(e1) / 1e3 / iters
-        fl = 2.0 * Creal * 9 * O * H * W                 # algorithmic: the real input channels only
+        if li < ff:
+            continue
+        dt = acc[li] / iters / 1e3
+        fl = 2.0 * L['C'] * 9 * L['O'] * L['H'] * L['W']          # algorithmic: the real input channels only
         per_layer.append(dict(layer=li, ms=dt * 1e3, tflops=fl / dt / 1e12))
         tot_t += dt
         tot_f += fl
         n += 1
-        del keep
     return tot_f / n, tot_t / n, per_layer
 
 

@@ -44,6 +44,9 @@ struct orn_engine {
     const void *g_frames, *g_embeds, *g_sched, *g_cursor, *g_stats;
     int g_slots;
     hipStream_t g_stream;
+    // orn_engine_profile_step: HIP events around every forward conv launch of an eager step
+    bool prof;
+    hipEvent_t prof_ev[2 * ORN_MAX_LAYERS];
 };
 
 #define ORN_GRAPH_UNROLL 4
@@ -191,6 +194,8 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
     e->params = params; e->grads = grads; e->m = adam_m; e->v = adam_v;
     e->ws = (float *)ws;
     e->graph = nullptr; e->graph_exec = nullptr; e->graph_u = nullptr; e->graph_exec_u = nullptr;
+    e->prof = false;
+    for (int i = 0; i < 2 * ORN_MAX_LAYERS; ++i) e->prof_ev[i] = nullptr;
     e->ops = (d->precision == 2) ? orn_half_ops_f16() : orn_half_ops_bf16();
     e->gs = (d->precision == 2) ? 1048576.0f : 1.0f;
     layout(d, e);
@@ -233,6 +238,8 @@ extern "C" void orn_engine_destroy(orn_engine *e)
     if (e->graph) (void)hipGraphDestroy(e->graph);
     if (e->graph_exec_u) (void)hipGraphExecDestroy(e->graph_exec_u);
     if (e->graph_u) (void)hipGraphDestroy(e->graph_u);
+    for (int i = 0; i < 2 * ORN_MAX_LAYERS; ++i)
+        if (e->prof_ev[i]) (void)hipEventDestroy(e->prof_ev[i]);
     delete e;
 }
 
@@ -298,11 +305,15 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
         const orn_layer_desc &l = d.layer[i];
         LayerBuf &b = e->L[i];
         if (i < ff) {
+            if (e->prof) (void)hipEventRecord(e->prof_ev[2 * i], st);
             ORN_TRY(orn_launch_conv3x3_f32(x, b.wf, b.bf, 1, l.C, l.O, l.H, l.W, l.s, 1, keep_z ? b.z : nullptr, b.a, st, nullptr));
+            if (e->prof) (void)hipEventRecord(e->prof_ev[2 * i + 1], st);
             x = b.a;
         } else {
             if (i == ff) ORN_TRY(e->ops->to_nhwc(x, l.C, ORN_FAST_C, l.H, l.W, b.xpad, st));
+            if (e->prof) (void)hipEventRecord(e->prof_ev[2 * i], st);
             ORN_TRY(e->ops->conv_fwd(b.xpad, b.wb, b.biasp, l.H, l.W, ORN_FAST_C, l.O, l.s, b.zb, (i + 1 < nl) ? e->L[i + 1].xpad : nullptr, st));
+            if (e->prof) (void)hipEventRecord(e->prof_ev[2 * i + 1], st);
         }
     }
     if (ff < nl)
@@ -391,6 +402,35 @@ extern "C" int orn_engine_train_step(orn_engine *e, const float *frames, const f
     ORN_REQUIRE(e && frames && embeds && sched && cursor, "engine_train_step: null pointer");
     ORN_REQUIRE(e->grads && e->m && e->v, "engine_train_step: engine was created without grads / Adam arenas");
     return train_step(e, frames, embeds, sched, cursor, stats_out, n_slots, (hipStream_t)stream);
+}
+
+// One EAGER training step with HIP events around every layer's forward conv launch, on the launch stream:
+// ms_out[i] = duration of layer i's forward conv kernel inside a real step (bench.py's roofline leg).  Synchronises.
+extern "C" int orn_engine_profile_step(orn_engine *e, const float *frames, const float *embeds, const orn_step_sched *sched,
+                                       int32_t *cursor, float *stats_out, int32_t n_slots, float *ms_out, void *stream)
+{
+    ORN_REQUIRE(e && frames && embeds && sched && cursor && ms_out, "engine_profile_step: null pointer");
+    ORN_REQUIRE(e->grads && e->m && e->v, "engine_profile_step: engine was created without grads / Adam arenas");
+    hipStream_t st = (hipStream_t)stream;
+    const int nl = e->d.n_layers;
+    for (int i = 0; i < 2 * nl; ++i)
+        if (!e->prof_ev[i]) {
+            hipError_t rc = hipEventCreate(&e->prof_ev[i]);
+            if (rc != hipSuccess) { orn_set_error("engine_profile_step: hipEventCreate: %s", hipGetErrorString(rc)); return (int)rc; }
+        }
+    e->prof = true;
+    const int trc = train_step(e, frames, embeds, sched, cursor, stats_out, n_slots, st);
+    e->prof = false;
+    if (trc != 0) return trc;
+    hipError_t rc = hipStreamSynchronize(st);
+    if (rc != hipSuccess) { orn_set_error("engine_profile_step: sync: %s", hipGetErrorString(rc)); return (int)rc; }
+    for (int i = 0; i < nl; ++i) {
+        float ms = 0.f;
+        rc = hipEventElapsedTime(&ms, e->prof_ev[2 * i], e->prof_ev[2 * i + 1]);
+        if (rc != hipSuccess) { orn_set_error("engine_profile_step: elapsed: %s", hipGetErrorString(rc)); return (int)rc; }
+        ms_out[i] = ms;
+    }
+    return 0;
 }
 
 extern "C" int orn_engine_train_steps_graph(orn_engine *e, const float *frames, const float *embeds,

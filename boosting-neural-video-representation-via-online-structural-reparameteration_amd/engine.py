@@ -181,6 +181,23 @@ class TrainEngine:
         cur.wait_stream(self.stream)
         self.global_step += n_steps
 
+    def profile_step(self):
+        """One eager optimiser step with HIP events around every layer's forward conv launch, on the engine's stream:
+        returns the per-layer kernel durations in ms (host list).  Consumes one schedule entry; synchronises."""
+        if self.frames is None or self.sched is None:
+            raise OrnError('set_video() and set_schedule() first')
+        import ctypes
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        n = self.desc.n_layers
+        ms = (ctypes.c_float * n)()
+        check(lib().orn_engine_profile_step(self._h, _lib.ptr(self.frames), _lib.ptr(self.embeds), _lib.ptr(self.sched),
+                                            _lib.ptr(self.cursor), _lib.ptr(self.stats_ring), c_int32(self.n_slots), ms,
+                                            c_void_p(self.stream.cuda_stream)), 'orn_engine_profile_step')
+        cur.wait_stream(self.stream)
+        self.global_step += 1
+        return [float(x) for x in ms]
+
     def stats(self, n: int) -> torch.Tensor:
         """[n,8] host tensor of the last run's first n steps: loss, L1, MSE, SSIM, PSNR, lr, frame, step."""
         return self.stats_ring[:n].cpu()

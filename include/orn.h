@@ -192,6 +192,10 @@ int orn_engine_decode(orn_engine *e, const float *embed, float *img, void *strea
 int orn_engine_train_step(orn_engine *e, const float *frames, const float *embeds,
                           const orn_step_sched *sched, int32_t *cursor, float *stats_out, int32_t n_slots,
                           void *stream);
+/* One eager training step with HIP events around every layer's forward conv launch (ms_out[n_layers], host);
+ * synchronises the stream.  Measurement hook for bench.py's roofline leg -- no reference counterpart. */
+int orn_engine_profile_step(orn_engine *e, const float *frames, const float *embeds, const orn_step_sched *sched,
+                            int32_t *cursor, float *stats_out, int32_t n_slots, float *ms_out, void *stream);
 /* Capture one train step into a hipGraph on `stream` and replay it n times (same arguments as above). */
 int orn_engine_train_steps_graph(orn_engine *e, const float *frames, const float *embeds,
                                  const orn_step_sched *sched, int32_t *cursor, float *stats_out,
