@@ -5,10 +5,13 @@
 // caller (PyTorch is only the allocator).
 #include "orn_internal.h"
 #include <new>
+#include <cstdlib>
 
 struct LayerBuf {
     float *T, *wf, *bf;   // merge products (ERB) -- wf/bf alias the params for vanilla/deploy
     float *dT, *dw1p;     // merge backward scratch (ERB)
+    void *mh16;           // half operand copies of the merge backward (16-bit modes, orn_merge_h16.hip)
+    float *dw2t;          // dW2 tap-major [9][O][2C] (16-bit modes)
     float *z, *a;         // block output (pre-activation, activation)          [fp32 layers]
     float *da;            // gradient wrt the block output                       [fp32 layers]
     // bf16 fast path (precision 1, layers >= ff): channels-last bf16, see orn_conv_bf16.hip
@@ -34,6 +37,7 @@ struct orn_engine {
     const OrnHalfOps *ops;           // 16-bit fast-path kernels (bf16 or fp16 build)
     float gs;                        // gradient scale carried by the 16-bit gradient tensors (1 for bf16, 2^20 for fp16)
     void *merge_tables;              // device-resident grouped-GEMM problem tables (ERB)
+    void *mh_tables, *mh_host;       // 16-bit modes: tables of the packed-operand merge backward (device / host)
     int merge_tiles[4];
     int ff;                          // first layer on the bf16 fast path (== n_layers: none)
     float *dxn;                      // fp32 NHWC dgrad output of layer ff (converted to NCHW for the fp32 part)
@@ -124,6 +128,10 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
         if (d->erb) {
             L[i].T = take(wsz); L[i].wf = take(wsz); L[i].bf = take(l.O);
             L[i].dT = take(wsz); L[i].dw1p = take((size_t)9 * 2 * l.C * l.C);
+            if (d->precision != 0) {
+                L[i].mh16 = take((orn_merge_h16_layer_halfs(l.C, l.O) + 1) / 2);
+                L[i].dw2t = take((size_t)9 * l.O * 2 * l.C);
+            }
         }
         Cn = l.O / (l.s * l.s); H = l.H * l.s; W = l.W * l.s;
         const size_t asz = (size_t)Cn * H * W;
@@ -157,6 +165,7 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
     float *scr = take(scratch);
     float *cur = take(16);
     float *mtab = d->erb ? take(orn_merge_group_bytes() / 4) : nullptr;
+    float *mhtab = (d->erb && d->precision != 0) ? take(orn_merge_h16_table_bytes() / 4) : nullptr;
     if (e) {
         e->pre1 = pre1; e->h1 = h1; e->pre2 = pre2; e->h2 = h2; e->dh2 = dh2;
         e->img = img; e->dimg = dimg; e->stats = stats; e->loss_ws = loss_ws; e->scratch = scr;
@@ -165,6 +174,7 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
         e->Hout = H; e->Wout = W; e->Cn_last = Cn;
         e->ff = ff; e->dxn = dxn;
         e->merge_tables = mtab;
+        e->mh_tables = mhtab;
     }
     return off * 4;
 }
@@ -195,6 +205,7 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
     e->ws = (float *)ws;
     e->graph = nullptr; e->graph_exec = nullptr; e->graph_u = nullptr; e->graph_exec_u = nullptr;
     e->prof = false;
+    e->mh_host = nullptr;
     for (int i = 0; i < 2 * ORN_MAX_LAYERS; ++i) e->prof_ev[i] = nullptr;
     e->ops = (d->precision == 2) ? orn_half_ops_f16() : orn_half_ops_bf16();
     e->gs = (d->precision == 2) ? 1048576.0f : 1.0f;
@@ -222,9 +233,16 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
             m.g = grads ? grads + l.w3x3 : nullptr;
             m.dT = e->L[i].dT; m.dw1p = e->L[i].dw1p;
             m.dw2 = grads ? grads + l.w2 : nullptr; m.dw3 = grads ? grads + l.w3 : nullptr;
+            m.dw2t = e->L[i].dw2t;
         }
-        const int rc = orn_merge_groups_build(e->merge_tables, d->n_layers, ml, d->precision != 0);
-        if (rc != 0) { delete e; return rc; }
+        int rc = orn_merge_groups_build(e->merge_tables, d->n_layers, ml, d->precision != 0);
+        if (rc == 0 && d->precision != 0) {
+            void *bufs[ORN_MAX_LAYERS];
+            for (int i = 0; i < d->n_layers; ++i) bufs[i] = e->L[i].mh16;
+            e->mh_host = malloc(orn_merge_h16_host_bytes());
+            rc = e->mh_host ? orn_merge_h16_build(e->mh_tables, e->mh_host, d->n_layers, ml, bufs) : ORN_E_ARG;
+        }
+        if (rc != 0) { free(e->mh_host); delete e; return rc; }
         for (int k = 0; k < 4; ++k) e->merge_tiles[k] = orn_merge_group_tiles(k, d->n_layers, ml);
     }
     *out = e;
@@ -240,6 +258,7 @@ extern "C" void orn_engine_destroy(orn_engine *e)
     if (e->graph_u) (void)hipGraphDestroy(e->graph_u);
     for (int i = 0; i < 2 * ORN_MAX_LAYERS; ++i)
         if (e->prof_ev[i]) (void)hipEventDestroy(e->prof_ev[i]);
+    free(e->mh_host);
     delete e;
 }
 
@@ -376,8 +395,12 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
     }
     if (d.erb) {
         // merge backward of every layer (closed forms): dW3 & dT, then dW2 & dW1, then the slices
-        ORN_TRY(orn_launch_merge_group(e->merge_tables, 2, e->merge_tiles[2], st));
-        ORN_TRY(orn_launch_merge_group(e->merge_tables, 3, e->merge_tiles[3], st));
+        if (d.precision != 0) {
+            ORN_TRY(orn_launch_merge_h16_bwd(e->mh_tables, e->mh_host, st));
+        } else {
+            ORN_TRY(orn_launch_merge_group(e->merge_tables, 2, e->merge_tiles[2], st));
+            ORN_TRY(orn_launch_merge_group(e->merge_tables, 3, e->merge_tiles[3], st));
+        }
         OrnMergeMisc mm[ORN_MAX_LAYERS];
         for (int i = 0; i < nl; ++i) {
             const orn_layer_desc &l = d.layer[i];
@@ -386,6 +409,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
             mm[i].g = G + l.w3x3; mm[i].dbf = G + l.b3x3; mm[i].dw1p = e->L[i].dw1p;
             mm[i].d3x1 = G + l.w3x1; mm[i].db3x1 = G + l.b3x1; mm[i].d1x3 = G + l.w1x3; mm[i].db1x3 = G + l.b1x3;
             mm[i].dw1 = G + l.w1;
+            if (d.precision != 0) { mm[i].dw2t = e->L[i].dw2t; mm[i].dw2 = G + l.w2; }
         }
         ORN_TRY(orn_launch_merge_bwd_tail_all(nl, mm, st));
     }

@@ -31,6 +31,7 @@ struct OrnMergeLayer {
     float *T, *wf;                                    // forward products
     const float *g;                                   // dL/dWf (in the gradient arena)
     float *dT, *dw1p, *dw2, *dw3;                     // backward scratch / outputs
+    float *dw2t;                                      // 16-bit modes: dW2 tap-major [9][O][2C], interleaved by the tail kernel
 };
 size_t orn_merge_group_bytes();
 int orn_merge_groups_build(void *dev_tables, int n_layers, const OrnMergeLayer *L, int bwd_h16);
@@ -40,12 +41,20 @@ int orn_launch_merge_bias(const float *b3x3, const float *b1x3, const float *b3x
 int orn_launch_merge_bwd_tail(const float *g, const float *dbf, int C, int O, float *d3x3, float *db3x3, float *d3x1,
                               float *db3x1, float *d1x3, float *db1x3, const float *dw1p, float *dw1, hipStream_t st);
 
+// orn_merge_h16.hip: merge backward GEMMs of the 16-bit engine modes (packed half operands, fragments from global)
+size_t orn_merge_h16_layer_halfs(int C, int O);
+size_t orn_merge_h16_table_bytes();
+size_t orn_merge_h16_host_bytes();
+int orn_merge_h16_build(void *dev_tables, void *host, int n_layers, const OrnMergeLayer *L, void *const *bufs);
+int orn_launch_merge_h16_bwd(const void *dev_tables, const void *host, hipStream_t st);
+
 // per-layer elementwise tails of the merge, all layers per launch
 struct OrnMergeMisc {
     int C, O;
     const float *b3x3, *b1x3, *b3x1; float *bf;                       // forward bias
     const float *g, *dbf, *dw1p;                                      // backward inputs (dWf, dbf live in the grad arena)
     float *d3x1, *db3x1, *d1x3, *db1x3, *dw1;                         // backward outputs
+    const float *dw2t; float *dw2;                                    // optional: dW2 [9][O][2C] -> [O][2C][3][3]
 };
 int orn_launch_merge_bias_all(int n, const OrnMergeMisc *L, hipStream_t st);
 int orn_launch_merge_bwd_tail_all(int n, const OrnMergeMisc *L, hipStream_t st);

@@ -502,6 +502,16 @@ __global__ void k_merge_bwd_tail_all(MiscLayers m)
         for (int k = 0; k < 9; ++k) acc += l.dw1p[(long)k * n1 + i];
         l.dw1[i] = acc;
     }
+    if (l.dw2t) {                                  // tap-major GEMM output -> the parameter's [O][2C][3][3] layout
+        const long n2 = (long)l.O * 2 * l.C;
+        for (long j = i; j < n2; j += (long)gridDim.x * blockDim.x) {
+            float v[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) v[k] = l.dw2t[(long)k * n2 + j];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) l.dw2[j * 9 + k] = v[k];
+        }
+    }
 }
 
 int orn_launch_merge_bias_all(int n, const OrnMergeMisc *L, hipStream_t st)
