@@ -13,7 +13,8 @@ class OrnError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(HERE, 'liborn.so')
+    # ORN_LIB_PATH: A/B timing of two builds on one GPU box (tools/probes); the default is the in-tree library
+    return os.environ.get('ORN_LIB_PATH') or os.path.join(HERE, 'liborn.so')
 
 
 class LayerDesc(ctypes.Structure):

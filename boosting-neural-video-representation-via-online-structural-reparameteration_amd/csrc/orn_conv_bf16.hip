@@ -731,22 +731,30 @@ struct PrepAll {
     struct { const float *wf, *bf; int O, C, Cp, Cn, s2; h16 *wb, *wd; float *biasp; } l[ORN_MAX_LAYERS];   // Cp: channel stride
 };
 
-__global__ void k_prep_weights_bf16_all(PrepAll a)
+// PREP_EPT elements per thread: a launch of one-element work-groups is bound by the dispatcher (~500 work-groups/us)
+#define PREP_EPT 4
+__global__ void __launch_bounds__(256) k_prep_weights_bf16_all(PrepAll a)
 {
     const auto &l = a.l[blockIdx.y];
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < (size_t)l.O) {
-        const int o = (int)idx;
+    const size_t base = (size_t)blockIdx.x * (256 * PREP_EPT) + threadIdx.x;
+    const size_t bidx = (size_t)blockIdx.x * 256 + threadIdx.x;     // the grid has >= O / 256 blocks (C * 9 >= PREP_EPT)
+    if (bidx < (size_t)l.O) {
+        const int o = (int)bidx;
         l.biasp[(o % l.s2) * l.Cn + o / l.s2] = l.bf[o];
     }
-    if (idx >= (size_t)l.O * l.C * 9) return;
-    const int tap = (int)(idx % 9);
-    const size_t oc = idx / 9;
-    const int c = (int)(oc % l.C), o = (int)(oc / l.C);
-    const int op = (o % l.s2) * l.Cn + o / l.s2;
-    const h16 v = (h16)l.wf[idx];
-    l.wb[((size_t)tap * l.O + op) * l.Cp + c] = v;
-    l.wd[((size_t)(8 - tap) * l.Cp + c) * l.O + op] = v;
+    const size_t n = (size_t)l.O * l.C * 9;
+#pragma unroll
+    for (int i = 0; i < PREP_EPT; ++i) {
+        const size_t idx = base + (size_t)i * 256;
+        if (idx >= n) return;
+        const int tap = (int)(idx % 9);
+        const size_t oc = idx / 9;
+        const int c = (int)(oc % l.C), o = (int)(oc / l.C);
+        const int op = (o % l.s2) * l.Cn + o / l.s2;
+        const h16 v = (h16)l.wf[idx];
+        l.wb[((size_t)tap * l.O + op) * l.Cp + c] = v;
+        l.wd[((size_t)(8 - tap) * l.Cp + c) * l.O + op] = v;
+    }
 }
 
 int orn_launch_prep_weights_bf16_all(int n, const OrnPrepLayer *L, hipStream_t st)
@@ -763,7 +771,7 @@ int orn_launch_prep_weights_bf16_all(int n, const OrnPrepLayer *L, hipStream_t s
         const size_t w = (size_t)L[i].O * L[i].C * 9;
         if (w > mx) mx = w;
     }
-    hipLaunchKernelGGL(k_prep_weights_bf16_all, dim3(orn_cdiv((long)mx, 256), n), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_prep_weights_bf16_all, dim3(orn_cdiv((long)mx, 256 * PREP_EPT), n), dim3(256), 0, st, a);
     ORN_LAUNCH_CHECK("prep_weights_bf16_all");
     return 0;
 }

@@ -152,16 +152,18 @@ __global__ void k_linear_silu_bwd_w(const float *__restrict__ x, const int *__re
                                     const float *__restrict__ pre, const float *__restrict__ dy, int B, int K, int N,
                                     float *__restrict__ dpre, float *__restrict__ dw, float *__restrict__ db)
 {
-    const int o = blockIdx.x;
+    // one output row per wave (a row per work-group makes thousands of tiny work-groups: dispatcher-bound)
+    const int o = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (o >= N) return;
     if (row_idx) x += (size_t)(*row_idx) * row_stride;
     float dsum = 0.f;
     for (int b = 0; b < B; ++b) {
         const float d = dy[(size_t)b * N + o] * orn_silu_grad_exact(pre[(size_t)b * N + o]);
         dsum += d;
-        if (threadIdx.x == 0) dpre[(size_t)b * N + o] = d;
+        if (lane == 0) dpre[(size_t)b * N + o] = d;
     }
-    if (threadIdx.x == 0) db[o] = dsum;
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    if (lane == 0) db[o] = dsum;
+    for (int k = lane; k < K; k += 64) {
         float acc = 0.f;
         for (int b = 0; b < B; ++b) {
             const float d = dy[(size_t)b * N + o] * orn_silu_grad_exact(pre[(size_t)b * N + o]);
@@ -222,7 +224,7 @@ int orn_launch_stem_bwd(const float *embed, const int *row_idx, size_t row_strid
     float *dpre1 = dpre2 + (size_t)B * Nout;
     float *dh1 = dpre1 + (size_t)B * Hd;
     float *partial = dh1 + (size_t)B * Hd;
-    hipLaunchKernelGGL(k_linear_silu_bwd_w, dim3(Nout), dim3(256), 0, st, h1, nullptr, 0, pre2, dh2, B, Hd, Nout,
+    hipLaunchKernelGGL(k_linear_silu_bwd_w, dim3(orn_cdiv(Nout, 4)), dim3(256), 0, st, h1, nullptr, 0, pre2, dh2, B, Hd, Nout,
                        dpre2, dw1, db1);
     ORN_LAUNCH_CHECK("stem_bwd_w1");
     const int rpc = orn_cdiv(Nout, ORN_STEM_CHUNKS);
@@ -236,7 +238,7 @@ int orn_launch_stem_bwd(const float *embed, const int *row_idx, size_t row_strid
         return 0;
     }
     ORN_TRY(orn_launch_reduce_rows(partial, ORN_STEM_CHUNKS, (size_t)B * Hd, (size_t)B * Hd, dh1, st));
-    hipLaunchKernelGGL(k_linear_silu_bwd_w, dim3(Hd), dim3(128), 0, st, embed, row_idx, row_stride, pre1, dh1, B, E, Hd,
+    hipLaunchKernelGGL(k_linear_silu_bwd_w, dim3(orn_cdiv(Hd, 2)), dim3(128), 0, st, embed, row_idx, row_stride, pre1, dh1, B, E, Hd,
                        dpre1, dw0, db0);
     ORN_LAUNCH_CHECK("stem_bwd_w0");
     return 0;
