@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(256) k_ssim_stats(LossP q)
 {
     __shared__ __attribute__((aligned(16))) float Ps[SS_PH][SS_PWP];
     __shared__ __attribute__((aligned(16))) float Ts[SS_PH][SS_PWP];
-    __shared__ float Hs[5][SS_PH][SS_TW];
+    __shared__ __attribute__((aligned(16))) float Hs[5][SS_PH][SS_TW];
     __shared__ float sred[16];
     const int t = threadIdx.x;
     const int plane = blockIdx.y;
@@ -91,11 +91,12 @@ __global__ void __launch_bounds__(256) k_ssim_stats(LossP q)
                 }
             }
         }
-#pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            Hs[0][r][c4 + o] = sp[o]; Hs[1][r][c4 + o] = st[o]; Hs[2][r][c4 + o] = spp[o];
-            Hs[3][r][c4 + o] = stt[o]; Hs[4][r][c4 + o] = spt[o];
-        }
+        // 16-byte stores: scalar ones put the 4 rows of a wave on the same 16 banks (4-way conflicts)
+        *reinterpret_cast<float4 *>(&Hs[0][r][c4]) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+        *reinterpret_cast<float4 *>(&Hs[1][r][c4]) = make_float4(st[0], st[1], st[2], st[3]);
+        *reinterpret_cast<float4 *>(&Hs[2][r][c4]) = make_float4(spp[0], spp[1], spp[2], spp[3]);
+        *reinterpret_cast<float4 *>(&Hs[3][r][c4]) = make_float4(stt[0], stt[1], stt[2], stt[3]);
+        *reinterpret_cast<float4 *>(&Hs[4][r][c4]) = make_float4(spt[0], spt[1], spt[2], spt[3]);
     }
     __syncthreads();
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
@@ -141,7 +142,7 @@ __global__ void __launch_bounds__(256) k_ssim_stats(LossP q)
 __global__ void __launch_bounds__(256) k_loss_grad(LossP q)
 {
     __shared__ __attribute__((aligned(16))) float Ds[3][SS_PH][SS_PWP];
-    __shared__ float Hh[3][SS_PH][SS_TW];
+    __shared__ __attribute__((aligned(16))) float Hh[3][SS_PH][SS_TW];
     __shared__ float sred[16];
     const int t = threadIdx.x;
     const int plane = blockIdx.y;
@@ -185,13 +186,15 @@ __global__ void __launch_bounds__(256) k_loss_grad(LossP q)
                     const float4 v = *reinterpret_cast<const float4 *>(&Ds[m][r][c4 + 4 * k]);
                     w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
                 }
+                float hv[4];
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
                     float acc = 0.f;
 #pragma unroll
                     for (int k = 0; k < 11; ++k) acc = fmaf(c_gauss[k], w[o + 10 - k], acc);
-                    Hh[m][r][c4 + o] = acc;
+                    hv[o] = acc;
                 }
+                *reinterpret_cast<float4 *>(&Hh[m][r][c4]) = make_float4(hv[0], hv[1], hv[2], hv[3]);
             }
         }
         __syncthreads();
