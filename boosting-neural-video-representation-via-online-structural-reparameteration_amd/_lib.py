@@ -70,6 +70,7 @@ _SIGS = {
     'orn_engine_train_step': (c_int, [P, P, P, P, P, P, c_int32, P]),
     'orn_engine_train_steps_graph': (c_int, [P, P, P, P, P, P, c_int32, c_int32, P]),
     'orn_engine_profile_step': (c_int, [P, P, P, P, P, P, c_int32, P, P]),
+    'orn_engine_set_grad_mask': (c_int, [P, P]),
     'orn_engine_fused_kernel': (c_int, [P, c_int, POINTER(c_void_p), POINTER(c_void_p)]),
 }
 EXPORTS = tuple(_SIGS.keys())

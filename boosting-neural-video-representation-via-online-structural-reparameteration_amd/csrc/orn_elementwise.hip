@@ -454,8 +454,10 @@ extern "C" int orn_head_bwd(const float *a, const float *w, const float *out, co
 // step_size / sqrt_bc2 come by value (per-op API) or from the engine's device-side step state.
 __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
                        size_t n, float step_size_v, float sqrt_bc2_v, const OrnStepCur *__restrict__ sp, float beta1,
-                       float omb1, float beta2, float omb2, float eps, float inv_gscale)
+                       float omb1, float beta2, float omb2, float eps, float inv_gscale, const float *__restrict__ gmask)
 {
+    // gmask (optional, 0/1 per parameter): the gradient is multiplied by it -- the prune fine-tune of main_eval.py,
+    // where a masked weight (weight_orig * mask) only ever receives the masked gradient and a frozen tensor none
     float step_size = step_size_v, sqrt_bc2 = sqrt_bc2_v;
     if (sp) { step_size = sp->step_size; sqrt_bc2 = sp->sqrt_bc2; }
     const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -469,7 +471,7 @@ __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float
         const float *gp = &gv.x;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float gg = gp[k] * inv_gscale;
+            const float gg = gp[k] * inv_gscale * (gmask ? gmask[i0 + k] : 1.0f);
             mp[k] = __fadd_rn(__fmul_rn(beta1, mp[k]), __fmul_rn(omb1, gg));
             vp[k] = __fadd_rn(__fmul_rn(beta2, vp[k]), __fmul_rn(__fmul_rn(omb2, gg), gg));
             pp[k] -= step_size * (mp[k] / (sqrtf(vp[k]) / sqrt_bc2 + eps));
@@ -479,7 +481,7 @@ __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float
         *reinterpret_cast<float4 *>(v + i0) = vv;
     } else {
         for (size_t i = i0; i < n; ++i) {
-            const float gg = g[i] * inv_gscale;
+            const float gg = g[i] * inv_gscale * (gmask ? gmask[i] : 1.0f);
             const float mm = __fadd_rn(__fmul_rn(beta1, m[i]), __fmul_rn(omb1, gg));
             const float vv = __fadd_rn(__fmul_rn(beta2, v[i]), __fmul_rn(__fmul_rn(omb2, gg), gg));
             m[i] = mm;
@@ -490,12 +492,12 @@ __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float
 }
 
 int orn_launch_adam(float *p, const float *g, float *m, float *v, size_t n, double lr, int step, const OrnStepCur *sp,
-                    double beta1, double beta2, double eps, float inv_gscale, hipStream_t st)
+                    double beta1, double beta2, double eps, float inv_gscale, hipStream_t st, const float *gmask)
 {
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     hipLaunchKernelGGL(k_adam, dim3(orn_cdiv((long)orn_cdiv((long)n, 4), 256)), dim3(256), 0, st, p, g, m, v, n,
                        (float)(lr / bc1), (float)sqrt(bc2), sp, (float)beta1, (float)(1.0 - beta1), (float)beta2,
-                       (float)(1.0 - beta2), (float)eps, inv_gscale);
+                       (float)(1.0 - beta2), (float)eps, inv_gscale, gmask);
     ORN_LAUNCH_CHECK("adam");
     return 0;
 }
@@ -505,5 +507,5 @@ extern "C" int orn_adam_step(float *p, const float *g, float *m, float *v, size_
 {
     ORN_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
     ORN_REQUIRE(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, "adam_step: arenas must be 16-byte aligned");
-    return orn_launch_adam(p, g, m, v, n, lr, step, nullptr, beta1, beta2, eps, 1.0f, (hipStream_t)stream);
+    return orn_launch_adam(p, g, m, v, n, lr, step, nullptr, beta1, beta2, eps, 1.0f, (hipStream_t)stream, nullptr);
 }

@@ -25,6 +25,7 @@ struct LayerBuf {
 struct orn_engine {
     orn_engine_desc d;
     float *params, *grads, *m, *v;
+    const float *gmask;              // optional 0/1 gradient mask (prune fine-tune), same layout as the arenas
     float *ws;
     // workspace carve
     float *pre1, *h1, *pre2, *h2, *dh2;
@@ -202,6 +203,7 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
     ORN_REQUIRE(e, "engine_create: out of host memory");
     e->d = *d;
     e->params = params; e->grads = grads; e->m = adam_m; e->v = adam_v;
+    e->gmask = nullptr;
     e->ws = (float *)ws;
     e->graph = nullptr; e->graph_exec = nullptr; e->graph_u = nullptr; e->graph_exec_u = nullptr;
     e->prof = false;
@@ -260,6 +262,20 @@ extern "C" void orn_engine_destroy(orn_engine *e)
         if (e->prof_ev[i]) (void)hipEventDestroy(e->prof_ev[i]);
     free(e->mh_host);
     delete e;
+}
+
+// Optional 0/1 mask multiplied into the gradients before Adam (null: none).  Changes what a captured step does, so
+// the graph cache is dropped.  main_eval.py:213-531 (prune fine-tune): pruned weights keep a zero gradient.
+extern "C" int orn_engine_set_grad_mask(orn_engine *e, const float *mask)
+{
+    ORN_REQUIRE(e, "engine_set_grad_mask: null engine");
+    ORN_REQUIRE((uintptr_t)mask % 16 == 0, "engine_set_grad_mask: mask must be 16-byte aligned");
+    e->gmask = mask;
+    if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+    if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
+    if (e->graph_exec_u) { (void)hipGraphExecDestroy(e->graph_exec_u); e->graph_exec_u = nullptr; }
+    if (e->graph_u) { (void)hipGraphDestroy(e->graph_u); e->graph_u = nullptr; }
+    return 0;
 }
 
 extern "C" int orn_engine_fused_kernel(orn_engine *e, int layer, const float **wf, const float **bf)
@@ -415,7 +431,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
     }
     ORN_TRY(orn_launch_stem_bwd(embeds, fidx, d.embed_len, P + d.stem_w1, e->pre1, e->h1, e->pre2, e->dh2, 1, d.embed_len,
                                 d.stem_dim, Nout, G + d.stem_w0, G + d.stem_b0, G + d.stem_w1, G + d.stem_b1, e->scratch, st));
-    ORN_TRY(orn_launch_adam(P, G, e->m, e->v, (size_t)d.n_params, 0.0, 1, e->cur, d.beta1, d.beta2, d.eps, 1.0f, st));
+    ORN_TRY(orn_launch_adam(P, G, e->m, e->v, (size_t)d.n_params, 0.0, 1, e->cur, d.beta1, d.beta2, d.eps, 1.0f, st, e->gmask));
     return 0;
 }
 

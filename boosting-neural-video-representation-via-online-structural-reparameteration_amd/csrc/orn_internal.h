@@ -14,7 +14,7 @@ int orn_launch_head_fwd(const float *a, const float *w, const float *b, int B, i
 int orn_launch_head_bwd(const float *a, const float *w, const float *out, const float *dout, int B, int C, size_t HW,
                         int sigmoid, float *da, float *dw, float *db, float *ws, hipStream_t st);
 int orn_launch_adam(float *p, const float *g, float *m, float *v, size_t n, double lr, int step, const OrnStepCur *sp,
-                    double beta1, double beta2, double eps, float inv_gscale, hipStream_t st);
+                    double beta1, double beta2, double eps, float inv_gscale, hipStream_t st, const float *gmask = nullptr);
 
 // orn_merge.hip
 int orn_launch_merge_fwd(const float *w3x3, const float *b3x3, const float *w3x1, const float *b3x1,

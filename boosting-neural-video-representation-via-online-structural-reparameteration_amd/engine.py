@@ -181,6 +181,20 @@ class TrainEngine:
         cur.wait_stream(self.stream)
         self.global_step += n_steps
 
+    def set_grad_mask(self, masks=None):
+        """0/1 gradient masks per parameter name ({name: tensor like the parameter}; missing names = 1); None removes
+        the mask.  Used by the prune fine-tune (main_eval.py:213-531)."""
+        if masks is None:
+            self._gmask = None
+            check(lib().orn_engine_set_grad_mask(self._h, None), 'orn_engine_set_grad_mask')
+            return
+        gm = torch.ones(self.n_params, device=self.device)
+        for k, m in masks.items():
+            off, n = self.layout[k]
+            gm[off:off + n] = m.to(self.device, torch.float32).reshape(-1)
+        self._gmask = gm                                    # keep alive: the engine holds the raw pointer
+        check(lib().orn_engine_set_grad_mask(self._h, _lib.ptr(gm)), 'orn_engine_set_grad_mask')
+
     def profile_step(self):
         """One eager optimiser step with HIP events around every layer's forward conv launch, on the engine's stream:
         returns the per-layer kernel durations in ms (host list).  Consumes one schedule entry; synchronises."""

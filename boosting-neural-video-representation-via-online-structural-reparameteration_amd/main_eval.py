@@ -2,8 +2,13 @@
 load `model_latest(.pth|_deploy.pth)` -> global L1 prune (--prune_ratio) -> switch to deploy -> per-axis 8-bit
 quantisation + Huffman size estimate (--quant_bit) -> decode every frame (PSNR, decoder FPS, bits per pixel).
 
-Scope note: the reference's optional prune *fine-tune* loop (main_eval.py:450-531) is not reproduced -- with ERB
-it trains no conv weights at a near-zero LR; `--finetune` raises NotImplementedError."""
+`--finetune` (main_eval.py:213-545): load the TRAIN-mode checkpoint, prune the stem Linear weights and every conv
+branch weight together (global L1), fine-tune `--finetune_epochs` on the native engine, then deploy/quantise/evaluate.
+The reference's behaviour is kept, quirks included: Q1 -- with ERB the online merge reads `.weight`
+directly, so torch's pruning hooks never fire and the branch conv weights stay frozen at their pruned-at-t0 values
+(only stem weights under their mask, all biases and the head train); NeRV_vanilla convs train under their masks.
+Q2 -- the LR comes from adjust_lr(epoch % total_epochs) with epoch continuing from the checkpoint (>= args.epochs),
+i.e. the cosine evaluated past its end (0 at e = 300, 4e-5 x lr at 301, ...).  Q3 is `quantize_per_tensor`'s."""
 import os
 import time
 
@@ -13,19 +18,77 @@ from . import checkpoint, data as odata, eval_utils, model as omodel, ops, utils
 from .main_train import build_parser
 
 
+ERB_BRANCHES = ('rbr_3x3_branch', 'rbr_3x1_branch', 'rbr_1x3_branch', 'rbr_1x1_3x3_1x1_branch_1x1_1',
+                'rbr_1x1_3x3_1x1_branch_3x3', 'rbr_1x1_3x3_1x1_branch_1x1_2')
+
+
+def _prune_finetune(model, args, PE, ckpt_path):
+    """main_eval.py:213-531 on the native engine (see the module docstring for the reference quirks kept)."""
+    from . import engine as oeng
+    named = dict(model.named_parameters())
+    prunable = {}
+    for k in named:                                            # main_eval.py:296-302: stem Linear weights
+        if k.startswith('stem.') and k.endswith('weight'):
+            prunable[k] = named[k].detach()
+    for i, blk in enumerate(model.layers):                     # main_eval.py:305-340 (ERB) / 244-264 (vanilla)
+        names = ERB_BRANCHES if blk.branch_type == 'ERB' else ('branch',)
+        for b in names:
+            k = f'layers.{i}.{b}.weight'
+            if k in named:
+                prunable[k] = named[k].detach()
+    masks = eval_utils.global_l1_prune_masks(prunable, args.prune_ratio)
+    zero = sum(int((m == 0).sum()) for m in masks.values())
+    tot = sum(m.numel() for m in masks.values())
+    print(f'global L1 prune of {len(masks)} tensors: {zero}/{tot} = {zero / tot:.3f} (asked {args.prune_ratio})')
+    with torch.no_grad():
+        for k, m in masks.items():
+            named[k].mul_(m)
+    eng = oeng.TrainEngine(model, loss_type=args.loss_type, beta=args.beta, precision=args.precision)
+    gmask = {}
+    for k, m in masks.items():                                 # Q1: ERB branch convs are frozen, the rest trains masked
+        frozen = k.startswith('layers.') and args.branch_type == 'ERB'
+        gmask[k] = torch.zeros_like(m) if frozen else m
+    eng.set_grad_mask(gmask)
+    hw = eng.out_hw
+    frames = (odata.synthetic_video(args.synthetic, hw[0], hw[1], seed=1234) if args.synthetic
+              else odata.load_png_dir(f'../data/{args.dataset.lower()}', args.vid, args.frame_gap))
+    n = frames.shape[0]
+    eng.set_video(frames, PE(torch.tensor([float(k) / n for k in range(n)], dtype=torch.float32)))
+    try:
+        start_epoch = int(torch.load(ckpt_path, map_location='cpu', weights_only=True).get('epoch', args.epochs))
+    except Exception:
+        start_epoch = args.epochs
+    total = start_epoch + args.finetune_epochs
+    g = torch.Generator()
+    step = 0
+    for epoch in range(start_epoch, total):
+        g.manual_seed(args.manualSeed + epoch)
+        order = torch.randperm(n, generator=g).tolist()
+        entries = []
+        for i, f in enumerate(order):
+            step += 1                                          # fresh optimiser: main_eval.py:496 clears its state
+            entries.append((f, step, utils.lr_value(epoch % total, i, n, args)))      # Q2
+        eng.set_schedule(entries)
+        eng.run(n)
+        st = eng.stats(n)
+        if (epoch - start_epoch) % max(1, args.finetune_epochs // 10) == 0 or epoch == total - 1:
+            print(f'fine-tune epoch {epoch + 1}/{total} lr {float(st[-1, 5]):.2e} PSNR {float(st[:, 4].mean()):.2f}', flush=True)
+    eng.set_grad_mask(None)
+    torch.cuda.synchronize()
+
+
 def main(argv=None):
     p = build_parser()
     p.add_argument('--finetune', action='store_true')
     p.add_argument('--finetune_epochs', type=int, default=100)
     p.add_argument('--cycles', type=int, default=1)
     args = p.parse_args(argv)
-    if args.finetune:
-        raise NotImplementedError('prune fine-tuning (main_eval.py:450-531) is outside the built path; see module docstring')
     outf = os.path.join('result', args.outf, f'{args.suffix}')
     PE = utils.PositionalEncoding(args.embed)
     deploy_file = os.path.join(outf, 'model_latest_deploy.pth')
     train_file = os.path.join(outf, 'model_latest.pth')
-    path = deploy_file if (args.branch_type == 'ERB' and os.path.exists(deploy_file)) else train_file
+    finetune = args.finetune and args.prune_ratio < 1
+    path = deploy_file if (args.branch_type == 'ERB' and os.path.exists(deploy_file) and not finetune) else train_file
     if not os.path.exists(path):
         raise FileNotFoundError(path)
     sd = checkpoint.load_state_dict_file(path)
@@ -37,12 +100,14 @@ def main(argv=None):
                              branch_type=args.branch_type)
     kind = checkpoint.load_into(model, sd)
     model = model.cuda()
+    if finetune:
+        _prune_finetune(model, args, PE, path)
     if kind != 'deploy':
         for blk in model.layers:
             blk.switch_to_deploy() if blk.branch_type == 'ERB' else None
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     n_param = sum(v.numel() for v in sd.values())
-    if args.prune_ratio < 1:                       # main_eval.py:269-273: weights of stem / conv layers, global L1
+    if args.prune_ratio < 1 and not finetune:      # main_eval.py:551-650: prune the deploy-state weights, global L1
         prunable = {k: v for k, v in sd.items() if k.endswith('weight')}
         masks = eval_utils.global_l1_prune_masks(prunable, args.prune_ratio)
         for k, m in masks.items():

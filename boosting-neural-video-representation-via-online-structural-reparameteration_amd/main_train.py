@@ -75,7 +75,7 @@ def build_parser():
     p.add_argument('--outf', default='unify')
     p.add_argument('--suffix', default='')
     # additions of this engine
-    p.add_argument('--precision', default='bf16', choices=['fp32', 'bf16', 'fp16'])
+    p.add_argument('--precision', default='fp16', choices=['fp32', 'bf16', 'fp16'])
     p.add_argument('--synthetic', type=int, default=0, help='use N synthetic frames in HBM instead of ../data/<dataset>')
     p.add_argument('--ckpt_freq', type=int, default=0, help='checkpoint every K epochs (0: eval epochs and the last)')
     return p

@@ -192,6 +192,10 @@ int orn_engine_decode(orn_engine *e, const float *embed, float *img, void *strea
 int orn_engine_train_step(orn_engine *e, const float *frames, const float *embeds,
                           const orn_step_sched *sched, int32_t *cursor, float *stats_out, int32_t n_slots,
                           void *stream);
+/* Optional 0/1 gradient mask in the arena layout (device, float, 16-byte aligned; null removes it): gradients are
+ * multiplied by it before Adam.  The prune fine-tune of main_eval.py:213-531 -- torch.nn.utils.prune keeps
+ * weight = weight_orig * mask, so pruned entries never receive a gradient -- and its frozen tensors. */
+int orn_engine_set_grad_mask(orn_engine *e, const float *mask);
 /* One eager training step with HIP events around every layer's forward conv launch (ms_out[n_layers], host);
  * synchronises the stream.  Measurement hook for bench.py's roofline leg -- no reference counterpart. */
 int orn_engine_profile_step(orn_engine *e, const float *frames, const float *embeds, const orn_step_sched *sched,

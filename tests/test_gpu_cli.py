@@ -30,5 +30,24 @@ def test_train_then_eval_cli(tmp_path, monkeypatch):
     psnr_pq = main_eval.main(FLAGS + ['--prune_ratio', '0.4', '--quant_bit', '8'])
     assert abs(psnr_plain - best) < 3.0          # decode of the deploy file reproduces the training-time quality
     assert psnr_pq <= psnr_plain + 0.5 and psnr_pq > 5.0
-    with pytest.raises(NotImplementedError):
-        main_eval.main(FLAGS + ['--finetune'])
+    # BASELINE config 5: prune 0.4 -> fine-tune -> quantise.  Reference quirk Q1: with ERB the branch conv
+    # weights stay frozen at their pruned-at-t0 values; stem weights train under their mask; biases train.
+    before = checkpoint.load_state_dict_file(str(outf / 'model_latest.pth'))
+    captured = {}
+    orig = main_eval._prune_finetune
+
+    def spy(model, args, PE, path):
+        orig(model, args, PE, path)
+        captured.update({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    monkeypatch.setattr(main_eval, '_prune_finetune', spy)
+    psnr_ft = main_eval.main(FLAGS + ['--prune_ratio', '0.4', '--quant_bit', '8', '--finetune', '--finetune_epochs', '3'])
+    assert psnr_ft > 5.0
+    k = 'layers.3.rbr_1x1_3x3_1x1_branch_3x3.weight'
+    pruned = captured[k] == 0
+    assert 0.05 < float(pruned.float().mean()) < 0.95
+    assert torch.equal(captured[k][~pruned], before[k][~pruned])                 # frozen: survivors bit-unchanged
+    ks = 'stem.2.weight'
+    zs = captured[ks] == 0
+    assert float(zs.float().mean()) > 0.05 and not torch.equal(captured[ks][~zs], before[ks][~zs])   # masked, trained
+    kb = 'layers.3.rbr_3x3_branch.bias'
+    assert not torch.equal(captured[kb], before[kb])                             # biases train
