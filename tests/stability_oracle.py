@@ -1,7 +1,7 @@
 """Does the reference recipe (lr 5e-4, warmup 0.2, cosine, Adam(0.5, 0.999), Fusion6) stay stable on the synthetic
 video?  Runs the CPU oracle (reference math) on a small geometry with the full 300-epoch schedule shape."""
 import sys, os, time, math
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
 from oracle import cpu_ref
 

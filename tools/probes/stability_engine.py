@@ -1,5 +1,5 @@
 """Long-horizon stability of the engine on a chosen geometry: train PSNR per 10 epochs under the reference schedule
-(lr, warmup 0.2, cosine).  Pair with tests/stability_oracle.py (same data, same order) on the CPU."""
+(lr, warmup 0.2, cosine).  Pair with tests/stability_oracle.py (CPU oracle) (same data, same order) on the CPU."""
 import sys, os, time, argparse
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import torch
