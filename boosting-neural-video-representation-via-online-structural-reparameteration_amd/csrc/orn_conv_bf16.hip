@@ -731,8 +731,8 @@ struct PrepAll {
     struct { const float *wf, *bf; int O, C, Cp, Cn, s2; h16 *wb, *wd; float *biasp; } l[ORN_MAX_LAYERS];   // Cp: channel stride
 };
 
-// PREP_EPT elements per thread: a launch of one-element work-groups is bound by the dispatcher (~500 work-groups/us)
-#define PREP_EPT 4
+// PREP_EPT elements per thread (measured: 1 beats 4 here -- the scattered 2-byte writes, not the dispatcher, bound it)
+#define PREP_EPT 1
 __global__ void __launch_bounds__(256) k_prep_weights_bf16_all(PrepAll a)
 {
     const auto &l = a.l[blockIdx.y];

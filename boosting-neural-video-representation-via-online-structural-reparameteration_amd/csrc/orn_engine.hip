@@ -232,6 +232,7 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
             m.w3x3 = params + l.w3x3; m.w3x1 = params + l.w3x1; m.w1x3 = params + l.w1x3;
             m.w1 = params + l.w1; m.w2 = params + l.w2; m.w3 = params + l.w3;
             m.T = e->L[i].T; m.wf = e->L[i].wf;
+            m.b3x3 = params + l.b3x3; m.b1x3 = params + l.b1x3; m.b3x1 = params + l.b3x1; m.bf = e->L[i].bf;
             m.g = grads ? grads + l.w3x3 : nullptr;
             m.dT = e->L[i].dT; m.dw1p = e->L[i].dw1p;
             m.dw2 = grads ? grads + l.w2 : nullptr; m.dw3 = grads ? grads + l.w3 : nullptr;
@@ -319,14 +320,7 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
         // online re-parameterisation of every layer (model.py:534): weights only, so all layers up front
         ORN_TRY(orn_launch_merge_group(e->merge_tables, 0, e->merge_tiles[0], st));
         ORN_TRY(orn_launch_merge_group(e->merge_tables, 1, e->merge_tiles[1], st));
-        OrnMergeMisc mm[ORN_MAX_LAYERS];
-        for (int i = 0; i < nl; ++i) {
-            const orn_layer_desc &l = d.layer[i];
-            mm[i] = OrnMergeMisc{};
-            mm[i].C = l.C; mm[i].O = l.O;
-            mm[i].b3x3 = P + l.b3x3; mm[i].b1x3 = P + l.b1x3; mm[i].b3x1 = P + l.b3x1; mm[i].bf = e->L[i].bf;
-        }
-        ORN_TRY(orn_launch_merge_bias_all(nl, mm, st));
+        // (the bias merge b3x3 + (b1x3 + b3x1) rides in the S launch's first tile column)
     }
     if (ff < nl) {      // bf16 operand copies of every fast layer's merged kernel, one launch
         OrnPrepLayer pl[ORN_MAX_LAYERS];

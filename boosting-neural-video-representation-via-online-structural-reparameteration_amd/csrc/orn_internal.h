@@ -28,6 +28,7 @@ int orn_launch_merge_bwd(const float *g, const float *dbf, const float *w1, cons
 struct OrnMergeLayer {
     int C, O;
     const float *w3x3, *w3x1, *w1x3, *w1, *w2, *w3;   // parameters
+    const float *b3x3, *b1x3, *b3x1; float *bf;       // optional: bias merge folded into the S GEMM (null: separate launch)
     float *T, *wf;                                    // forward products
     const float *g;                                   // dL/dWf (in the gradient arena)
     float *dT, *dw1p, *dw2, *dw3;                     // backward scratch / outputs

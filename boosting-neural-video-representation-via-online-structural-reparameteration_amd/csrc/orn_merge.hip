@@ -19,6 +19,9 @@ struct GemmP {
     int epi;
     const float *w3x3, *w1x3, *w3x1;
     int Cch;
+    // epilogue 1, optional (engine): the first column of tiles also merges the bias, bf = b3x3 + (b1x3 + b3x1)
+    const float *b3x3, *b1x3, *b3x1;
+    float *bf;
     // 16-bit MFMA variant (merge backward in the 16-bit engine modes): operands are multiplied by sa / sb when they
     // are rounded to IEEE half (gradient operands ~1e-6 would be subnormal), the result by so = 1/(sa*sb)
     float sa, sb, so;
@@ -95,6 +98,13 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, int bx, int by, int bz
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk * GLDB], acc, 0, 0, 0);
     }
     const int gn = n0 + wn * 32 + l31;
+    if (p.epi == 1 && p.bf && bx == 0 && wn == 0 && l31 == 0) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int gm = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+            if (gm < p.M) p.bf[gm] = p.b3x3[gm] + (p.b1x3[gm] + p.b3x1[gm]);     // model.py:476,496
+        }
+    }
     if (gn >= p.N) return;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
@@ -406,7 +416,7 @@ int orn_merge_groups_build(void *dev_tables, int n_layers, const OrnMergeLayer *
     for (int i = 0; i < n_layers; ++i) {
         const OrnMergeLayer &l = L[i];
         group_add(h[0], prob_T(l.w1, l.w2, l.C, l.O, l.T), 9);
-        group_add(h[1], prob_S(l.w3x3, l.w3x1, l.w1x3, l.w3, l.T, l.C, l.O, l.wf), 1);
+        { GemmP q = prob_S(l.w3x3, l.w3x1, l.w1x3, l.w3, l.T, l.C, l.O, l.wf); q.b3x3 = l.b3x3; q.b1x3 = l.b1x3; q.b3x1 = l.b3x1; q.bf = l.bf; group_add(h[1], q, 1); }
         // gradient operands (dWf, dT ~ 1e-6) are scaled by 2^14 when rounded to half; weights are not
         const float GS = 16384.0f;
         GemmP q;
