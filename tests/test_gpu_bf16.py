@@ -169,3 +169,32 @@ def test_engine_is_run_to_run_deterministic(orn, prec):
     assert torch.equal(outs[0][2], outs[1][2])
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1])
+
+
+def test_profile_step_and_grad_mask(orn):
+    """orn_engine_profile_step returns a positive duration for every layer's forward conv launch and advances training
+    like a normal step; orn_engine_set_grad_mask freezes exactly the masked entries (Adam sees a zero gradient)."""
+    from oracle import cpu_ref
+    gen = _mk(orn, '2_3_26', [5, 2, 2], 96, 'ERB')
+    eng = orn.engine.TrainEngine(gen, loss_type='Fusion6', beta=0.5, precision='fp16')
+    hw = eng.out_hw
+    eng.set_video(cpu_ref.synthetic_video(3, hw[0], hw[1], seed=5),
+                  cpu_ref.positional_encoding(torch.tensor([k / 3 for k in range(3)]), 1.25, 40))
+    eng.set_schedule([(k % 3, k + 1, 5e-4) for k in range(4)])
+    name = 'layers.1.rbr_3x3_branch.weight'
+    off, n = eng.layout[name]
+    mask = (torch.rand(n, generator=torch.Generator().manual_seed(0)) > 0.5).float()
+    before = eng.params[off:off + n].clone()
+    eng.set_grad_mask({name: mask.view(tuple(dict(gen.named_parameters())[name].shape))})      # fresh Adam state: m = v = 0
+    eng.run(2, graph=True)
+    torch.cuda.synchronize()
+    after = eng.params[off:off + n]
+    frozen = mask.cuda() == 0
+    assert torch.equal(after[frozen], before[frozen]) and not torch.equal(after[~frozen], before[~frozen])
+    eng.set_grad_mask(None)
+    ms = eng.profile_step()
+    assert len(ms) == 3 and all(0.0 < m < 5.0 for m in ms), ms
+    eng.run(1, graph=True)
+    torch.cuda.synchronize()
+    assert not torch.equal(eng.params[off:off + n][frozen], before[frozen])
+    assert int(eng.stats(4)[3, 7]) == 4
