@@ -223,6 +223,21 @@ class TrainEngine:
         check(lib().orn_engine_decode(self._h, _lib.ptr(embed), _lib.ptr(img), _lib.stream()), 'orn_engine_decode')
         return img
 
+    def engine_fused_kernel(self, layer: int):
+        """(Wf, bf) of block `layer` exactly as the ENGINE's last merge left them in its workspace (copies; ERB only)."""
+        wf, bf = c_void_p(), c_void_p()
+        check(lib().orn_engine_fused_kernel(self._h, layer, byref(wf), byref(bf)), 'orn_engine_fused_kernel')
+        shape = tuple(dict(self.model.named_parameters())[f'layers.{layer}.rbr_3x3_branch.weight'].shape)
+        n = shape[0] * shape[1] * 9
+        torch.cuda.synchronize()
+        base = self.ws.data_ptr()
+
+        def view(ptr, cnt):                       # the pointers lie inside the engine's workspace tensor
+            off = ptr - base
+            assert 0 <= off and off + 4 * cnt <= self.ws.numel(), 'fused kernel pointer outside the workspace'
+            return self.ws[off:off + 4 * cnt].view(torch.float32).clone()
+        return view(wf.value, n).view(shape), view(bf.value, shape[0])
+
     def fused_kernel(self, layer: int):
         """(Wf, bf) of block `layer` as produced by the last merge (model.py:450-478), as tensors."""
         blk = self.model.layers[layer]

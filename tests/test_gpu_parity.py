@@ -419,6 +419,23 @@ def test_720p_gradients_vs_oracle(orn):
     assert rel[0][0] < 2e-3, rel[:8]
 
 
+def test_engine_merge_is_bit_exact(orn):
+    """The engine's grouped forward merge (all layers in two launches, bias folded into the S launch) against the per-op
+    merge (itself bit-exact vs oracle/merge_ref.c): identical bits for every layer of the 720p model, including the
+    26-channel layers with their K tails and edge tiles."""
+    torch.manual_seed(3)
+    gen = _make_720p(orn)
+    eng = orn.engine.TrainEngine(gen, loss_type='L2', beta=0.5, precision='fp16')
+    emb = torch.zeros(1, 80)
+    eng.decode(emb[0])
+    for li, blk in enumerate(gen.layers):
+        wf_e, bf_e = eng.engine_fused_kernel(li)
+        with torch.no_grad():
+            wf_o, bf_o = blk.get_equivalent_kernel_bias()
+        assert torch.equal(wf_e, wf_o), (li, float((wf_e - wf_o).abs().max()))
+        assert torch.equal(bf_e, bf_o), li
+
+
 def test_deploy_checkpoint_round_trip(orn, golden, tmp_path):
     """N1: a reference *_deploy.pth decodes frame-for-frame; our deploy export of a trained ERB model
     equals the reference's switch_to_deploy result and decodes identically through the engine's decode path."""
