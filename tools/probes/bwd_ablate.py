@@ -1,6 +1,7 @@
 """Timing of the bf16 wgrad / dgrad kernels at the L4 shape (+ timing-only ablations)."""
 import sys, torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from ctypes import c_void_p, c_int
 import orn_amd
 from orn_amd import _lib
@@ -27,11 +28,9 @@ def t(fn, n=10):
     for _ in range(n): fn()
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / n
-for rnd in range(2):
-    for f in (0, 1):
+names = {0: 'baseline', 1: 'no weight restage', 2: 'no patch stage', 4: 'no stores', 3: 'no global loads', 7: 'mfma+lds+barriers', 15: 'mfma+lds', 31: 'mfma only'}
+for rnd in range(3):
+    for f in (0, 2, 1, 4, 7, 31):
         lib.orn_debug_set(c_int(f))
-        ms = t(wgrad); print(f'round {rnd} wgrad flags {f}: {ms*1e3:.1f} us {152.9e9/ms/1e9:.0f} TF (incl. slab reduce)')
-    for f in (0, 3, 7, 31):
-        lib.orn_debug_set(c_int(f))
-        ms = t(dgrad); print(f'round {rnd} dgrad flags {f}: {ms*1e3:.1f} us {152.9e9/ms/1e9:.0f} TF')
+        ms = t(dgrad); print(f'round {rnd} dgrad flags {f} ({names[f]}): {ms*1e3:.1f} us {152.9e9/ms/1e9:.0f} TF')
 lib.orn_debug_set(c_int(0))
