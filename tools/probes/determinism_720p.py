@@ -1,8 +1,9 @@
-import sys, torch
-sys.path.insert(0, '.')
+"""Run-to-run bit-identity of 40 training steps at 720p (fresh engines, polluted allocator in between)."""
+import os, sys, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import bench
 outs = []
-for prec in ('fp32', 'fp32', 'bf16', 'bf16'):
+for prec in ('fp16', 'fp16', 'bf16', 'bf16'):
     eng = bench.make_engine(seed=1234, precision=prec, noise=0.0)
     eng.set_schedule(bench.schedule(40))
     eng.run(40)
