@@ -12,6 +12,9 @@ hdt = torch.float16 if prec == 'fp16' else torch.bfloat16
 fwd = lib.orn_conv_nhwc_f16_fwd if prec == 'fp16' else lib.orn_conv_nhwc_bf16_fwd
 st = _lib.stream()
 keep = []
+if len(sys.argv) > 2:                       # timing-only ablation flags of the conv kernel (results are wrong)
+    from ctypes import c_int
+    lib.orn_debug_set(c_int(int(sys.argv[2])))
 for rep in range(2):
     for (H, W, Cr, last) in ((45, 80, 26, False), (90, 160, 96, False), (180, 320, 96, False), (360, 640, 96, True)):
         C, O, s = 96, 384, 2
