@@ -71,6 +71,8 @@ __device__ __forceinline__ void swap_halves_f(float &a, float &b)
     b = __builtin_bit_cast(float, ub);
 }
 
+__device__ __forceinline__ int conv_div(int x, unsigned m) { return m ? (int)__umulhi((unsigned)x, m) : x; }
+
 struct ConvBP {
     const h16 *xpad;     // [H+2][W+2][Cin]
     const h16 *w;        // [9][Nout][Cin]
@@ -89,6 +91,9 @@ struct ConvBP {
     int sp;
     // EPI_B_DGRAD_F32
     float *dx_f32;       // [H][W][Nout]
+    // exact division by multiply-high for the epilogues' index math (a runtime integer division costs ~30 instructions,
+    // and 16 of them per N tile per lane were a measurable part of the forward kernel): conv_div / conv_magic
+    unsigned mCn, mS, mSp;
     int dbg;             // timing-only ablation flags (tools/probes): 1 no weight restage, 2 no patch stage, 4 no stores
 };
 
@@ -298,19 +303,20 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
                         unsigned za0 = pack_h16x2(va[0], va[1]), za1 = pack_h16x2(va[2], va[3]);
                         unsigned zb0 = pack_h16x2(vb[0], vb[1]), zb1 = pack_h16x2(vb[2], vb[3]);
                         swap_halves(za0, zb0); swap_halves(za1, zb1);
-                        const int ij = c8 / p.Cn, n = c8 - ij * p.Cn, si = ij / p.s, sj = ij - si * p.s;
+                        const int ij = conv_div(c8, p.mCn), n = c8 - ij * p.Cn;
+                        const int si = conv_div(ij, p.mS), sj = ij - si * p.s;
                         const int Ws = W * p.s, oh = gh * p.s + si, ow = gw * p.s + sj;
                         constexpr int DI_ = 0;
                         const int di = (EPI == EPI_B_FWD) ? ((i * NB + j) * 2 + k / 2) : DI_;
                         dz[di] = u32x4{za0, za1, zb0, zb1};
-                        dzo[di] = (int)(((size_t)oh * Ws + ow) * p.Cn + n);
+                        dzo[di] = (oh * Ws + ow) * p.Cn + n;                      // < 2^31: checked by the launcher
                         dok[di] = ok;
                         if (p.apad) {
                             unsigned aa0 = pack_h16x2(orn_silu(va[0]), orn_silu(va[1])), aa1 = pack_h16x2(orn_silu(va[2]), orn_silu(va[3]));
                             unsigned ab0 = pack_h16x2(orn_silu(vb[0]), orn_silu(vb[1])), ab1 = pack_h16x2(orn_silu(vb[2]), orn_silu(vb[3]));
                             swap_halves(aa0, ab0); swap_halves(aa1, ab1);
                             da[di] = u32x4{aa0, aa1, ab0, ab1};
-                            dao[di] = (int)(((size_t)(oh + 1) * (Ws + 2) + (ow + 1)) * p.Cn + n);
+                            dao[di] = ((oh + 1) * (Ws + 2) + (ow + 1)) * p.Cn + n;
                         }
                     } else {
                         float v[8];
@@ -326,7 +332,8 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
                                 h16x8 o8;
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) o8[e] = (h16)(v[e] * orn_silu_grad((float)zz[e]));
-                                const int sp = p.sp, ph = gh / sp, pw = gw / sp, sub = (gh - ph * sp) * sp + (gw - pw * sp);
+                                const int sp = p.sp, ph = conv_div(gh, p.mSp), pw = conv_div(gw, p.mSp);
+                                const int sub = (gh - ph * sp) * sp + (gw - pw * sp);
                                 *reinterpret_cast<h16x8 *>(p.dyprev + ((size_t)(ph + 1) * (W / sp + 2) + (pw + 1)) * (p.Nout * sp * sp) +
                                                            sub * p.Nout + c8) = o8;
                             }
@@ -382,6 +389,13 @@ static int launch_conv_cfg(const ConvBP &p, int n_tiles_total, hipStream_t st)
 
 void set_debug(int flags) { g_conv_dbg = flags; }
 
+// m with x / d == umulhi(x, m) for every 0 <= x < 2^16 and 2 <= d < 2^16 (m = ceil(2^32 / d): the error term
+// x * (m*d - 2^32) < 2^16 * 2^16); d == 1 is encoded as m = 0 (conv_div returns x)
+static unsigned conv_magic(int d)
+{
+    return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned long long)d - 1) / (unsigned long long)d);
+}
+
 // fwd: N tile 128 (waves 4x2, wave tile 64 px x 64 ch); dgrad: N = 96 in one tile (waves 8x1, 32 px x 96 ch)
 int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p, int H, int W, int Cin, int O, int s,
                              h16 *z, h16 *apad, hipStream_t st)
@@ -392,6 +406,8 @@ int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p
     p.xpad = xpad; p.w = wb; p.bias = bias_p; p.H = H; p.W = W; p.Cin = Cin; p.Nout = O;
     p.tiles_w = orn_cdiv(W, CB_TW); p.tiles_h = orn_cdiv(H, CB_TH);
     p.z = z; p.apad = apad; p.s = s; p.Cn = O / (s * s);
+    ORN_REQUIRE(O < 65536 && s < 65536 && (long)(H * s + 2) * (W * s + 2) * p.Cn < 2147483647L, "conv_bf16_fwd: sizes exceed the 32-bit index math");
+    p.mCn = conv_magic(p.Cn); p.mS = conv_magic(s);
     const int nt_total = O / 128;
     // One work-group per CU (LDS): keep a pixel tile's N tiles together (patch staged once) unless cutting them
     // apart fills the chip better.  Cost model in units of one N tile: rounds x (work + ~0.3 for the patch).
@@ -446,6 +462,8 @@ int orn_launch_conv_bf16_dgrad(const h16 *dypad, const h16 *wd, int H, int W, in
     p.tiles_w = orn_cdiv(W, CB_TW); p.tiles_h = orn_cdiv(H, CB_TH);
     p.n_tiles_per_wg = 1;
     p.zprev = zprev; p.dyprev = dyprev; p.sp = sp; p.dx_f32 = dx_f32;
+    ORN_REQUIRE(H < 65536 && W < 65536 && sp >= 1 && sp < 65536, "conv_bf16_dgrad: sizes exceed the epilogue's index math");
+    p.mSp = conv_magic(sp);
     if (dx_f32) {
         p.qsplit = (p.tiles_w * p.tiles_h < 128 && O / CB_CK > 1) ? 1 : 0;   // few pixel tiles: one work-group per input chunk
         if (!zprev) return launch_conv_cfg<8, 1, 1, 3, EPI_B_DGRAD_F32>(p, 1, st);
