@@ -210,6 +210,9 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
         }                                                                                                       \
         pending = false;                                                                                        \
     }
+    float *sbias = reinterpret_cast<float *>(smem + PATCH_LDS + 3 * BS_BYTES);     // [Nout] after the weight ring (EPI_B_FWD)
+    if (EPI == EPI_B_FWD)
+        for (int i = t; i < p.Nout; i += NT) sbias[i] = p.bias ? p.bias[i] : 0.f;   // visible after the first N tile's barriers
     for (int nti = 0; nti < nt_cnt; ++nti) {
         const int nt = nt0 + nti;
         // acc[i][j]: D rows = 32 output channels (A operand = weights), D cols = 32 pixels of one row
@@ -294,8 +297,9 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
                     const int c8 = cb + 8 * (k + hh);                   // the 8 channels this lane stores
                     if (EPI == EPI_B_FWD) {
                         float va[4], vb[4];
-                        const float4 ba = p.bias ? *reinterpret_cast<const float4 *>(p.bias + cb + 8 * k + 4 * hh) : make_float4(0, 0, 0, 0);
-                        const float4 bb = p.bias ? *reinterpret_cast<const float4 *>(p.bias + cb + 8 * (k + 1) + 4 * hh) : make_float4(0, 0, 0, 0);
+                        // bias from its LDS copy (a global load here would expose its latency once per N tile)
+                        const float4 ba = *reinterpret_cast<const float4 *>(sbias + cb + 8 * k + 4 * hh);
+                        const float4 bb = *reinterpret_cast<const float4 *>(sbias + cb + 8 * (k + 1) + 4 * hh);
                         va[0] = acc[i][j][4 * k + 0] + ba.x; va[1] = acc[i][j][4 * k + 1] + ba.y;
                         va[2] = acc[i][j][4 * k + 2] + ba.z; va[3] = acc[i][j][4 * k + 3] + ba.w;
                         vb[0] = acc[i][j][4 * k + 4] + bb.x; vb[1] = acc[i][j][4 * k + 5] + bb.y;
@@ -364,11 +368,13 @@ static int launch_conv_cfg(const ConvBP &p, int n_tiles_total, hipStream_t st)
 {
     constexpr int BN = WAVES_N * NB * 32;
     constexpr int NT = WAVES_M * WAVES_N * 64;
-    const size_t smem = 65536 + 3 * (size_t)BN * 192;
+    const size_t smem = 65536 + 3 * (size_t)BN * 192 + (EPI == EPI_B_FWD ? orn_align((size_t)p.Nout * 4) : 0);   // + bias copy
     auto kern = k_conv_nhwc_bf16<WAVES_M, WAVES_N, MB, NB, EPI>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        // opt in once for the largest request (bias copy up to 2048 channels)
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(65536 + 3 * (size_t)BN * 192 + 8192));
         if (e != hipSuccess) { orn_set_error("conv_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
@@ -406,7 +412,7 @@ int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p
     p.xpad = xpad; p.w = wb; p.bias = bias_p; p.H = H; p.W = W; p.Cin = Cin; p.Nout = O;
     p.tiles_w = orn_cdiv(W, CB_TW); p.tiles_h = orn_cdiv(H, CB_TH);
     p.z = z; p.apad = apad; p.s = s; p.Cn = O / (s * s);
-    ORN_REQUIRE(O < 65536 && s < 65536 && (long)(H * s + 2) * (W * s + 2) * p.Cn < 2147483647L, "conv_bf16_fwd: sizes exceed the 32-bit index math");
+    ORN_REQUIRE(O <= 2048 && s < 65536 && (long)(H * s + 2) * (W * s + 2) * p.Cn < 2147483647L, "conv_bf16_fwd: sizes exceed the 32-bit index math");
     p.mCn = conv_magic(p.Cn); p.mS = conv_magic(s);
     const int nt_total = O / 128;
     // One work-group per CU (LDS): keep a pixel tile's N tiles together (patch staged once) unless cutting them
