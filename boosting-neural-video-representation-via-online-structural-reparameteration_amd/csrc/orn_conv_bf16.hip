@@ -987,13 +987,35 @@ k_head_bwd_nhwc_bf16(const h16 *__restrict__ z, const float *__restrict__ w, con
         for (int e = 0; e < 8; ++e) { dwacc[q][e][0] = 0.f; dwacc[q][e][1] = 0.f; dwacc[q][e][2] = 0.f; }
     float dbacc[3] = {0.f, 0.f, 0.f};
     const int Wp = W / sp + 2, Cp = C * sp * sp;
-    for (size_t pix = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2); pix < HW; pix += (size_t)gridDim.x * 64) {
+    // software pipeline: the next pixel's operands (3 x 16 B of z, out / dout) are requested before this pixel's ~500
+    // VALU instructions, so each iteration no longer starts with an exposed HBM round trip
+    const size_t pstep = (size_t)gridDim.x * 64;
+    size_t pix = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+    h16x8 vn[NQ];
+    float on[3], gn[3];
+    if (pix < HW) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) vn[q] = *reinterpret_cast<const h16x8 *>(z + pix * C + (q * 4 + sub) * 8);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { on[k] = out[(size_t)k * HW + pix]; gn[k] = dout[(size_t)k * HW + pix]; }
+    }
+    for (; pix < HW; pix += pstep) {
+        h16x8 vc[NQ];
         float du[3];
 #pragma unroll
+        for (int q = 0; q < NQ; ++q) vc[q] = vn[q];
+#pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float o = out[(size_t)k * HW + pix], g = dout[(size_t)k * HW + pix];
+            const float o = on[k], g = gn[k];
             du[k] = g * gs_up * (sigmoid ? o * (1.0f - o) : 2.0f * o * (1.0f - o));
             dbacc[k] += du[k];
+        }
+        const size_t pnx = pix + pstep;
+        if (pnx < HW) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) vn[q] = *reinterpret_cast<const h16x8 *>(z + pnx * C + (q * 4 + sub) * 8);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { on[k] = out[(size_t)k * HW + pnx]; gn[k] = dout[(size_t)k * HW + pnx]; }
         }
         const int h = (int)(pix / W), ww = (int)(pix - (size_t)h * W);
         const int ph = h / sp, pw = ww / sp;
@@ -1001,7 +1023,7 @@ k_head_bwd_nhwc_bf16(const h16 *__restrict__ z, const float *__restrict__ w, con
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int c0 = (q * 4 + sub) * 8;
-            const h16x8 v = *reinterpret_cast<const h16x8 *>(z + pix * C + c0);
+            const h16x8 v = vc[q];
             h16x8 o8;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
