@@ -943,11 +943,30 @@ k_head_fwd_nhwc_bf16(const h16 *__restrict__ z, const float *__restrict__ w, con
     __syncthreads();
     const int sub = threadIdx.x & 3;
     const int nq = C / 32;
-    for (size_t pix = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2); pix < HW; pix += (size_t)gridDim.x * 64) {
+    // software pipeline (nq <= 4, i.e. C <= 128): the next pixel's z is requested before this pixel's arithmetic
+    const size_t pstep = (size_t)gridDim.x * 64;
+    size_t pix = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+    const bool piped = nq <= 4;
+    h16x8 vn[4];
+    if (piped && pix < HW) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < nq) vn[q] = *reinterpret_cast<const h16x8 *>(z + pix * C + (q * 4 + sub) * 8);
+    }
+    for (; pix < HW; pix += pstep) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        for (int q = 0; q < nq; ++q) {
-            const int c0 = (q * 4 + sub) * 8;
-            const h16x8 v = *reinterpret_cast<const h16x8 *>(z + pix * C + c0);
+        h16x8 vc[4];
+        if (piped) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vc[q] = vn[q];
+            const size_t pnx = pix + pstep;
+            if (pnx < HW) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q < nq) vn[q] = *reinterpret_cast<const h16x8 *>(z + pnx * C + (q * 4 + sub) * 8);
+            }
+        }
+        auto proc = [&](const h16x8 v, int c0) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float a = orn_silu((float)v[e]);
@@ -955,6 +974,13 @@ k_head_fwd_nhwc_bf16(const h16 *__restrict__ z, const float *__restrict__ w, con
                 a1 = fmaf(sw[C + c0 + e], a, a1);
                 a2 = fmaf(sw[2 * C + c0 + e], a, a2);
             }
+        };
+        if (piped) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q < nq) proc(vc[q], (q * 4 + sub) * 8);
+        } else {
+            for (int q = 0; q < nq; ++q) proc(*reinterpret_cast<const h16x8 *>(z + pix * C + (q * 4 + sub) * 8), (q * 4 + sub) * 8);
         }
         a0 += __shfl_xor(a0, 1, 64); a1 += __shfl_xor(a1, 1, 64); a2 += __shfl_xor(a2, 1, 64);
         a0 += __shfl_xor(a0, 2, 64); a1 += __shfl_xor(a1, 2, 64); a2 += __shfl_xor(a2, 2, 64);
