@@ -129,14 +129,25 @@ def main(argv=None):
     psnrs = []
     torch.cuda.synchronize()
     t0 = time.time()
+    dumped = []
     with torch.no_grad():
         for k in range(n):
             img = model(embeds[k:k + 1])[0]
             st, _ = ops.loss_stats(img, frames[k:k + 1], 'L2', want_grad=False)
             psnrs.append(st[4])
+            if args.dump_images:                      # main_eval.py:795-803 (written after the timed loop)
+                dumped.append(img[0].detach())
     torch.cuda.synchronize()
     fps = n / (time.time() - t0)
     psnr = float(torch.stack(psnrs).mean())
+    if args.dump_images:
+        from PIL import Image
+        visual_dir = os.path.join(outf, 'visualize')
+        os.makedirs(visual_dir, exist_ok=True)
+        print(f'Saving predictions to {visual_dir}')
+        for k, im in enumerate(dumped):              # torchvision.utils.save_image: x*255 + 0.5, clamp, uint8, HWC
+            arr = im.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to('cpu', torch.uint8).numpy()
+            Image.fromarray(arr).save(os.path.join(visual_dir, f'pred_{k}.png'))
     with torch.no_grad():                                            # untimed, as the FPS above is the decoder's
         ms = [utils.msssim_fn([model(embeds[k:k + 1])[0]], [frames[k:k + 1]])[0, 0] for k in range(n)]
     msg = f'Eval: PSNR {psnr:.2f} dB, MS-SSIM {float(torch.stack(ms).mean()):.4f}, decode {fps:.1f} FPS, params {n_param / 1e6:.3f} M'

@@ -27,7 +27,10 @@ def test_train_then_eval_cli(tmp_path, monkeypatch):
     sd = checkpoint.load_state_dict_file(str(outf / 'model_latest_deploy.pth'))
     assert checkpoint.state_dict_kind(sd) == 'deploy' and len(sd) == 4 + 5 * 2 + 2
     psnr_plain = main_eval.main(FLAGS)
-    psnr_pq = main_eval.main(FLAGS + ['--prune_ratio', '0.4', '--quant_bit', '8'])
+    psnr_pq = main_eval.main(FLAGS + ['--prune_ratio', '0.4', '--quant_bit', '8', '--dump_images'])
+    from PIL import Image
+    im = Image.open(outf / 'visualize' / 'pred_11.png')
+    assert im.size == (1280, 720) and im.mode == 'RGB'
     assert abs(psnr_plain - best) < 3.0          # decode of the deploy file reproduces the training-time quality
     assert psnr_pq <= psnr_plain + 0.5 and psnr_pq > 5.0
     # BASELINE config 5: prune 0.4 -> fine-tune -> quantise.  Reference quirk Q1: with ERB the branch conv
