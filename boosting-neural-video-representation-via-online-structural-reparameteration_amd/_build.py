@@ -40,7 +40,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def cc(job):
         s, o, extra = job
-        cmd = [HIPCC] + FLAGS + extra + ['-c', s, '-o', o]
+        # ORN_CONV_ABLATE=1 (with force=True): timing-ablation flags of the conv kernels for tools/probes/*_ablate.py
+        abl = ['-DORN_CONV_ABLATE'] if os.environ.get('ORN_CONV_ABLATE') == '1' else []
+        cmd = [HIPCC] + FLAGS + extra + abl + ['-c', s, '-o', o]
         if verbose:
             print(' '.join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -34,6 +34,13 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 namespace HNS {
 
+// The timing-ablation flags cost registers and branches in the hot loops: they are compiled in only with
+// -DORN_CONV_ABLATE (tools/probes builds); product builds see a constant 0.
+#ifdef ORN_CONV_ABLATE
+#define PDBG(p_) ((p_).dbg)
+#else
+#define PDBG(p_) 0
+#endif
 static int g_conv_dbg = 0;   // timing experiments only (tools/probes), see orn_debug_set
 
 #define CB_TH 8
@@ -228,7 +235,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
         // prologue: every wave is done with the previous N tile's buffers -> DMA the patch (first N tile or
         // multi-chunk input) and weight tiles 0, 1; tile 2 stays in flight behind the first barrier.
         BARRIER();
-        if ((nti == 0 || Q > 1) && !(p.dbg & 2)) DMA_PATCH(0)
+        if ((nti == 0 || Q > 1) && !(PDBG(p) & 2)) DMA_PATCH(0)
         DMA_B(0, nt, 0, 0)
         if (n_tiles > 1) DMA_B(1, nt, 0, 1)
         WAIT_VM(0);
@@ -253,7 +260,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
             READ_FRAGS(fa[0], fb[0], buf, 0)
 #pragma unroll
             for (int ks = 0; ks < CB_CK / 16; ++ks) {
-                if (ks + 1 < CB_CK / 16 && !(p.dbg & 16)) READ_FRAGS(fa[(ks + 1) & 1], fb[(ks + 1) & 1], buf, ks + 1)
+                if (ks + 1 < CB_CK / 16 && !(PDBG(p) & 16)) READ_FRAGS(fa[(ks + 1) & 1], fb[(ks + 1) & 1], buf, ks + 1)
 #pragma unroll
                 for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -266,13 +273,13 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
                     else if (B_PER_WAVE == 3) WAIT_VM(3); else WAIT_VM(2);
                 }
                 else WAIT_VM(0);
-                if (!(p.dbg & 8)) BARRIER();
+                if (!(PDBG(p) & 8)) BARRIER();
                 if (!same_chunk) {                  // everyone is done with the old chunk's patch
-                    if (!(p.dbg & 2)) DMA_PATCH(qn)
+                    if (!(PDBG(p) & 2)) DMA_PATCH(qn)
                     WAIT_VM(0);
                     BARRIER();
                 }
-                if (tt + 3 < n_tiles && !(p.dbg & 1)) {
+                if (tt + 3 < n_tiles && !(PDBG(p) & 1)) {
                     const int q3 = (tt + 3) / 9, tap3 = (tt + 3) - q3 * 9;
                     DMA_B(buf, nt, q3, tap3)        // buffer of tile tt: free now
                 }
@@ -288,7 +295,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
             const int gh = h0 + wm * MB + i;
-            const bool ok = (gh < H) && (gw < W) && !(p.dbg & 4);
+            const bool ok = (gh < H) && (gw < W) && !(PDBG(p) & 4);
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const int cb = nt * BN + (wn * NB + j) * 32;            // first output channel of the block
@@ -585,7 +592,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p)
         const int h0_ = th_ * WB_TH, w0_ = tw_ * WB_TW;                                                         \
         _Pragma("unroll") for (int k = 0; k < DY_PW; ++k) {                                                     \
             const int gh = h0_ + dy_px[k] / WB_TW, gw = w0_ + (dy_px[k] & (WB_TW - 1));                         \
-            const bool ok = gh < H && gw < W && !(p.dbg & 1);                                                   \
+            const bool ok = gh < H && gw < W && !(PDBG(p) & 1);                                                   \
             const h16 *src = ok ? p.dypad + ((size_t)(gh + 1) * (W + 2) + (gw + 1)) * O + o0 + dy_c[k] * 8      \
                                 : p.dypad + dy_c[k] * 8; /* border pixel (0,0): zeros */                        \
             WDMA16(src, (buf_) * WB_BUF_BYTES + (uwave + 4 * k) * 1024);                                        \
@@ -594,7 +601,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p)
             if (uwave + 4 * k < WB_X_INSTR) {                                                                   \
                 const int r = x_px[k] / WB_XW, c = x_px[k] - r * WB_XW;                                         \
                 const int gh = h0_ + r + ti, gw = w0_ + c;                                                      \
-                const bool ok = x_px[k] < WB_TH * WB_XW && gh < H + 2 && gw < W + 2 && !(p.dbg & 1);            \
+                const bool ok = x_px[k] < WB_TH * WB_XW && gh < H + 2 && gw < W + 2 && !(PDBG(p) & 1);            \
                 const h16 *src = ok ? p.xpad + ((size_t)gh * (W + 2) + gw) * 96 + x_c[k] * 8 : p.xpad + x_c[k] * 8; \
                 WDMA16(src, (buf_) * WB_BUF_BYTES + WB_DY_BYTES + (uwave + 4 * k) * 1024);                      \
             }                                                                                                   \

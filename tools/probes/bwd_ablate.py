@@ -1,4 +1,5 @@
-"""Timing of the bf16 wgrad / dgrad kernels at the L4 shape (+ timing-only ablations)."""
+"""(needs a library built with ORN_CONV_ABLATE=1: python -c "import os; os.environ['ORN_CONV_ABLATE']='1'; from orn_amd import _build; _build.build(force=True)")
+Timing of the bf16 wgrad / dgrad kernels at the L4 shape (+ timing-only ablations)."""
 import sys, torch
 import os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
