@@ -52,7 +52,10 @@ static int g_conv_dbg = 0;   // timing experiments only (tools/probes), see orn_
 #define CB_PATCH_BYTES (CB_PH * CB_PW * CB_PIXB)
 #define CB_ROWB 208              // LDS bytes per weight-tile row
 
-enum { EPI_B_FWD = 0, EPI_B_DGRAD = 1, EPI_B_DGRAD_F32 = 2 };
+// EPI_B_FWD_LAST: the forward of the last block (no activation copy for a next layer): its own instantiation, so the
+// largest launch of the step carries neither the second set of deferred-store registers nor the SiLU code
+enum { EPI_B_FWD = 0, EPI_B_DGRAD = 1, EPI_B_DGRAD_F32 = 2, EPI_B_FWD_LAST = 3 };
+#define EPI_IS_FWD(e_) ((e_) == EPI_B_FWD || (e_) == EPI_B_FWD_LAST)
 
 typedef __attribute__((ext_vector_type(2))) h16 h16x2;
 __device__ __forceinline__ unsigned pack_h16x2(float lo, float hi)
@@ -202,7 +205,8 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
 
     // EPI_B_FWD: the packed outputs of an N tile are stored AFTER the next N tile's prologue rendezvous, so the
     // store drain overlaps the next main loop instead of stalling the prologue's vmcnt(0)
-    constexpr int NDEF = (EPI == EPI_B_FWD) ? MB * NB * 2 : 1;
+    constexpr bool APAD = (EPI == EPI_B_FWD);          // writes a = SiLU(z) into the next layer's padded input
+    constexpr int NDEF = EPI_IS_FWD(EPI) ? MB * NB * 2 : 1;
     u32x4 dz[NDEF], da[NDEF];
     int dzo[NDEF], dao[NDEF];
     bool dok[NDEF];
@@ -212,13 +216,13 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
         _Pragma("unroll") for (int e_ = 0; e_ < NDEF; ++e_) {                                                   \
             if (dok[e_]) {                                                                                      \
                 *reinterpret_cast<u32x4 *>(p.z + dzo[e_]) = dz[e_];                                             \
-                if (p.apad) *reinterpret_cast<u32x4 *>(p.apad + dao[e_]) = da[e_];                              \
+                if (APAD) *reinterpret_cast<u32x4 *>(p.apad + dao[e_]) = da[e_];                              \
             }                                                                                                   \
         }                                                                                                       \
         pending = false;                                                                                        \
     }
     float *sbias = reinterpret_cast<float *>(smem + PATCH_LDS + 3 * BS_BYTES);     // [Nout] after the weight ring (EPI_B_FWD)
-    if (EPI == EPI_B_FWD)
+    if (EPI_IS_FWD(EPI))
         for (int i = t; i < p.Nout; i += NT) sbias[i] = p.bias ? p.bias[i] : 0.f;   // visible after the first N tile's barriers
     for (int nti = 0; nti < nt_cnt; ++nti) {
         const int nt = nt0 + nti;
@@ -241,7 +245,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
         WAIT_VM(0);
         BARRIER();
         if (n_tiles > 2) DMA_B(2, nt, 0, 2)
-        if (EPI == EPI_B_FWD && pending) FLUSH_DEFERRED()
+        if (EPI_IS_FWD(EPI) && pending) FLUSH_DEFERRED()
         h16x8 fa[2][MB], fb[2][NB];
         int buf = 0;
         for (int tt = 0; tt < n_tiles; ++tt) {
@@ -302,7 +306,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
 #pragma unroll
                 for (int k = 0; k < 4; k += 2) {
                     const int c8 = cb + 8 * (k + hh);                   // the 8 channels this lane stores
-                    if (EPI == EPI_B_FWD) {
+                    if (EPI_IS_FWD(EPI)) {
                         float va[4], vb[4];
                         // bias from its LDS copy (a global load here would expose its latency once per N tile)
                         const float4 ba = *reinterpret_cast<const float4 *>(sbias + cb + 8 * k + 4 * hh);
@@ -318,11 +322,11 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
                         const int si = conv_div(ij, p.mS), sj = ij - si * p.s;
                         const int Ws = W * p.s, oh = gh * p.s + si, ow = gw * p.s + sj;
                         constexpr int DI_ = 0;
-                        const int di = (EPI == EPI_B_FWD) ? ((i * NB + j) * 2 + k / 2) : DI_;
+                        const int di = EPI_IS_FWD(EPI) ? ((i * NB + j) * 2 + k / 2) : DI_;
                         dz[di] = u32x4{za0, za1, zb0, zb1};
                         dzo[di] = (oh * Ws + ow) * p.Cn + n;                      // < 2^31: checked by the launcher
                         dok[di] = ok;
-                        if (p.apad) {
+                        if (APAD) {
                             unsigned aa0 = pack_h16x2(orn_silu(va[0]), orn_silu(va[1])), aa1 = pack_h16x2(orn_silu(va[2]), orn_silu(va[3]));
                             unsigned ab0 = pack_h16x2(orn_silu(vb[0]), orn_silu(vb[1])), ab1 = pack_h16x2(orn_silu(vb[2]), orn_silu(vb[3]));
                             swap_halves(aa0, ab0); swap_halves(aa1, ab1);
@@ -357,9 +361,9 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
                 }
             }
         }
-        if (EPI == EPI_B_FWD) pending = true;
+        if (EPI_IS_FWD(EPI)) pending = true;
     }
-    if (EPI == EPI_B_FWD && pending) FLUSH_DEFERRED()
+    if (EPI_IS_FWD(EPI) && pending) FLUSH_DEFERRED()
 }
 
 #undef FLUSH_DEFERRED
@@ -375,7 +379,7 @@ static int launch_conv_cfg(const ConvBP &p, int n_tiles_total, hipStream_t st)
 {
     constexpr int BN = WAVES_N * NB * 32;
     constexpr int NT = WAVES_M * WAVES_N * 64;
-    const size_t smem = 65536 + 3 * (size_t)BN * 192 + (EPI == EPI_B_FWD ? orn_align((size_t)p.Nout * 4) : 0);   // + bias copy
+    const size_t smem = 65536 + 3 * (size_t)BN * 192 + (EPI_IS_FWD(EPI) ? orn_align((size_t)p.Nout * 4) : 0);   // + bias copy
     auto kern = k_conv_nhwc_bf16<WAVES_M, WAVES_N, MB, NB, EPI>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -428,7 +432,7 @@ int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p
     const float cost_whole = (float)orn_cdiv(ptiles, 256) * nt_total;
     const float cost_split = (float)orn_cdiv(ptiles * nt_total, 256) * 1.3f;
     p.n_tiles_per_wg = (ptiles >= 512 || cost_whole <= cost_split) ? nt_total : 1;
-    return launch_conv_cfg<4, 2, 2, 2, EPI_B_FWD>(p, nt_total, st);
+    return apad ? launch_conv_cfg<4, 2, 2, 2, EPI_B_FWD>(p, nt_total, st) : launch_conv_cfg<4, 2, 2, 2, EPI_B_FWD_LAST>(p, nt_total, st);
 }
 
 // dx_f32 must hold orn_dgrad_f32_slabs(H, W, O) partial slabs of H*W*C floats; the NCHW convert sums them.
