@@ -452,6 +452,7 @@ extern "C" int orn_head_bwd(const float *a, const float *w, const float *out, co
 // Matches torch.optim.Adam's algebra:
 //   m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 // step_size / sqrt_bc2 come by value (per-op API) or from the engine's device-side step state.
+template <bool MASK>
 __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
                        size_t n, float step_size_v, float sqrt_bc2_v, const OrnStepCur *__restrict__ sp, float beta1,
                        float omb1, float beta2, float omb2, float eps, float inv_gscale, const float *__restrict__ gmask)
@@ -471,7 +472,7 @@ __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float
         const float *gp = &gv.x;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float gg = gp[k] * inv_gscale * (gmask ? gmask[i0 + k] : 1.0f);
+            const float gg = gp[k] * inv_gscale * (MASK ? gmask[i0 + k] : 1.0f);
             mp[k] = __fadd_rn(__fmul_rn(beta1, mp[k]), __fmul_rn(omb1, gg));
             vp[k] = __fadd_rn(__fmul_rn(beta2, vp[k]), __fmul_rn(__fmul_rn(omb2, gg), gg));
             pp[k] -= step_size * (mp[k] / (sqrtf(vp[k]) / sqrt_bc2 + eps));
@@ -481,7 +482,7 @@ __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float
         *reinterpret_cast<float4 *>(v + i0) = vv;
     } else {
         for (size_t i = i0; i < n; ++i) {
-            const float gg = g[i] * inv_gscale * (gmask ? gmask[i] : 1.0f);
+            const float gg = g[i] * inv_gscale * (MASK ? gmask[i] : 1.0f);
             const float mm = __fadd_rn(__fmul_rn(beta1, m[i]), __fmul_rn(omb1, gg));
             const float vv = __fadd_rn(__fmul_rn(beta2, v[i]), __fmul_rn(__fmul_rn(omb2, gg), gg));
             m[i] = mm;
@@ -495,9 +496,13 @@ int orn_launch_adam(float *p, const float *g, float *m, float *v, size_t n, doub
                     double beta1, double beta2, double eps, float inv_gscale, hipStream_t st, const float *gmask)
 {
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-    hipLaunchKernelGGL(k_adam, dim3(orn_cdiv((long)orn_cdiv((long)n, 4), 256)), dim3(256), 0, st, p, g, m, v, n,
-                       (float)(lr / bc1), (float)sqrt(bc2), sp, (float)beta1, (float)(1.0 - beta1), (float)beta2,
-                       (float)(1.0 - beta2), (float)eps, inv_gscale, gmask);
+    const dim3 gr(orn_cdiv((long)orn_cdiv((long)n, 4), 256));
+    if (gmask)
+        hipLaunchKernelGGL(k_adam<true>, gr, dim3(256), 0, st, p, g, m, v, n, (float)(lr / bc1), (float)sqrt(bc2), sp, (float)beta1,
+                           (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, inv_gscale, gmask);
+    else
+        hipLaunchKernelGGL(k_adam<false>, gr, dim3(256), 0, st, p, g, m, v, n, (float)(lr / bc1), (float)sqrt(bc2), sp, (float)beta1,
+                           (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, inv_gscale, gmask);
     ORN_LAUNCH_CHECK("adam");
     return 0;
 }

@@ -139,6 +139,8 @@ __global__ void __launch_bounds__(256) k_ssim_stats(LossP q)
     if (t == 0) q.part_ssim[(size_t)plane * gridDim.x + blockIdx.x] = tot;
 }
 
+// LT / GRAD are compile-time: the per-pixel loop carries no loss-type or null-pointer branches
+template <int LT, bool GRAD>
 __global__ void __launch_bounds__(256) k_loss_grad(LossP q)
 {
     __shared__ __attribute__((aligned(16))) float Ds[3][SS_PH][SS_PWP];
@@ -151,7 +153,7 @@ __global__ void __launch_bounds__(256) k_loss_grad(LossP q)
     const size_t HW = (size_t)q.H * q.W;
     const float *pp = q.pred + (size_t)plane * HW;
     const float *tp = q.target + (q.frame_idx ? (size_t)(*q.frame_idx) * q.frame_stride : 0) + (size_t)plane * HW;
-    const bool ssim = (q.loss_type == ORN_LOSS_FUSION6);
+    constexpr bool ssim = (LT == ORN_LOSS_FUSION6);
     if (ssim) {
         const size_t mo = (size_t)plane * q.Hv * q.Wv;
         {
@@ -208,9 +210,9 @@ __global__ void __launch_bounds__(256) k_loss_grad(LossP q)
         const float p = pp[o], tg = tp[o], d = p - tg;
         sabs += fabsf(d);
         ssq = fmaf(d, d, ssq);
-        if (q.dpred) {
+        if (GRAD) {
             float g = 0.f;
-            if (q.loss_type == ORN_LOSS_L2) g = q.g_l2 * d;
+            if (LT == ORN_LOSS_L2) g = q.g_l2 * d;
             else g = q.g_l1 * ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
             if (ssim) {
                 float am = 0.f, aq = 0.f, ar = 0.f;
@@ -346,7 +348,13 @@ int orn_launch_loss(const float *pred, const float *target, const int *frame_idx
         hipLaunchKernelGGL(k_ssim_stats, dim3(g.twv * g.thv, g.planes), dim3(256), 0, st, q);
         ORN_LAUNCH_CHECK("ssim_stats");
     }
-    hipLaunchKernelGGL(k_loss_grad, dim3(g.tw * g.th, g.planes), dim3(256), 0, st, q);
+    {
+        const dim3 gr(g.tw * g.th, g.planes), bl(256);
+        const bool gd = q.dpred != nullptr;
+        if (loss_type == ORN_LOSS_FUSION6) { if (gd) hipLaunchKernelGGL((k_loss_grad<ORN_LOSS_FUSION6, true>), gr, bl, 0, st, q); else hipLaunchKernelGGL((k_loss_grad<ORN_LOSS_FUSION6, false>), gr, bl, 0, st, q); }
+        else if (loss_type == ORN_LOSS_L2) { if (gd) hipLaunchKernelGGL((k_loss_grad<ORN_LOSS_L2, true>), gr, bl, 0, st, q); else hipLaunchKernelGGL((k_loss_grad<ORN_LOSS_L2, false>), gr, bl, 0, st, q); }
+        else { if (gd) hipLaunchKernelGGL((k_loss_grad<ORN_LOSS_L1, true>), gr, bl, 0, st, q); else hipLaunchKernelGGL((k_loss_grad<ORN_LOSS_L1, false>), gr, bl, 0, st, q); }
+    }
     ORN_LAUNCH_CHECK("loss_grad");
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, st, q.part_ssim, n_ssim, q.part_l1, g.planes * g.tw * g.th, n,
                        (double)g.nmap, loss_type, loss_scale, stats, cur, ring);
