@@ -206,6 +206,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
     // EPI_B_FWD: the packed outputs of an N tile are stored AFTER the next N tile's prologue rendezvous, so the
     // store drain overlaps the next main loop instead of stalling the prologue's vmcnt(0)
     constexpr bool APAD = (EPI == EPI_B_FWD);          // writes a = SiLU(z) into the next layer's padded input
+    constexpr int TAP_UNROLL = EPI_IS_FWD(EPI) ? 9 : 1;
     constexpr int NDEF = EPI_IS_FWD(EPI) ? MB * NB * 2 : 1;
     u32x4 dz[NDEF], da[NDEF];
     int dzo[NDEF], dao[NDEF];
@@ -248,7 +249,9 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
         if (EPI_IS_FWD(EPI) && pending) FLUSH_DEFERRED()
         h16x8 fa[2][MB], fb[2][NB];
         int buf = 0;
-        for (int tt = 0; tt < n_tiles; ++tt) {
+        // forward (one input chunk): nine taps, fully unrolled -- tap / row / ring-slot arithmetic folds to constants
+#pragma unroll TAP_UNROLL
+        for (int tt = 0; tt < (EPI_IS_FWD(EPI) ? 9 : n_tiles); ++tt) {
             const int q = tt / 9, tap = tt - q * 9;
             const int ti = tap / 3, tj = tap - ti * 3;
             const bool has_next = (tt + 1 < n_tiles);
