@@ -206,7 +206,6 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
     // EPI_B_FWD: the packed outputs of an N tile are stored AFTER the next N tile's prologue rendezvous, so the
     // store drain overlaps the next main loop instead of stalling the prologue's vmcnt(0)
     constexpr bool APAD = (EPI == EPI_B_FWD);          // writes a = SiLU(z) into the next layer's padded input
-    constexpr int TAP_UNROLL = EPI_IS_FWD(EPI) ? 9 : 1;
     constexpr int NDEF = EPI_IS_FWD(EPI) ? MB * NB * 2 : 1;
     u32x4 dz[NDEF], da[NDEF];
     int dzo[NDEF], dao[NDEF];
@@ -248,50 +247,54 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
         if (n_tiles > 2) DMA_B(2, nt, 0, 2)
         if (EPI_IS_FWD(EPI) && pending) FLUSH_DEFERRED()
         h16x8 fa[2][MB], fb[2][NB];
-        int buf = 0;
-        // forward (one input chunk): nine taps, fully unrolled -- tap / row / ring-slot arithmetic folds to constants
-#pragma unroll TAP_UNROLL
-        for (int tt = 0; tt < (EPI_IS_FWD(EPI) ? 9 : n_tiles); ++tt) {
-            const int q = tt / 9, tap = tt - q * 9;
-            const int ti = tap / 3, tj = tap - ti * 3;
-            const bool has_next = (tt + 1 < n_tiles);
-            const int qn = (tt + 1) / 9;
-            const bool same_chunk = has_next && (qn == q);
-            int a_row[MB], a_pos[MB];
+        // Chunks of 96 input channels outside, the nine taps inside and fully unrolled: tap, kernel row / column and the
+        // ring slot (tile 9q + tap -> slot tap % 3) fold to constants in every instantiation.
+        for (int q = 0; q < Q; ++q) {
 #pragma unroll
-            for (int i = 0; i < MB; ++i) {
-                const int pix = (wm * MB + i + ti) * CB_PW + l31 + tj;
-                a_row[i] = pix * ROWB;
-                a_pos[i] = 16 * (hh + ((pix >> 2) & 3));
-            }
-            READ_FRAGS(fa[0], fb[0], buf, 0)
+            for (int tap = 0; tap < 9; ++tap) {
+                const int tt = q * 9 + tap;
+                constexpr int dummy_ = 0; (void)dummy_;
+                const int buf = tap % 3;
+                const int ti = tap / 3, tj = tap - ti * 3;
+                const bool last_chunk = (q + 1 >= Q);
+                const bool has_next = (tap < 8) || !last_chunk;
+                const bool same_chunk = (tap < 8);
+                int a_row[MB], a_pos[MB];
 #pragma unroll
-            for (int ks = 0; ks < CB_CK / 16; ++ks) {
-                if (ks + 1 < CB_CK / 16 && !(PDBG(p) & 16)) READ_FRAGS(fa[(ks + 1) & 1], fb[(ks + 1) & 1], buf, ks + 1)
-#pragma unroll
-                for (int i = 0; i < MB; ++i)
-#pragma unroll
-                    for (int j = 0; j < NB; ++j) acc[i][j] = MFMA_H16(fb[ks & 1][j], fa[ks & 1][i], acc[i][j]);
-            }
-            if (has_next) {
-                // tile tt+1 was issued two tiles ago: let only tile tt+2's DMA stay in flight, then rendezvous
-                if (tt + 2 < n_tiles) {
-                    if (B_PER_WAVE == 6) WAIT_VM(6); else if (B_PER_WAVE == 5) WAIT_VM(5); else if (B_PER_WAVE == 4) WAIT_VM(4);
-                    else if (B_PER_WAVE == 3) WAIT_VM(3); else WAIT_VM(2);
+                for (int i = 0; i < MB; ++i) {
+                    const int pix = (wm * MB + i + ti) * CB_PW + l31 + tj;
+                    a_row[i] = pix * ROWB;
+                    a_pos[i] = 16 * (hh + ((pix >> 2) & 3));
                 }
-                else WAIT_VM(0);
-                if (!(PDBG(p) & 8)) BARRIER();
-                if (!same_chunk) {                  // everyone is done with the old chunk's patch
-                    if (!(PDBG(p) & 2)) DMA_PATCH(qn)
-                    WAIT_VM(0);
-                    BARRIER();
+                READ_FRAGS(fa[0], fb[0], buf, 0)
+#pragma unroll
+                for (int ks = 0; ks < CB_CK / 16; ++ks) {
+                    if (ks + 1 < CB_CK / 16 && !(PDBG(p) & 16)) READ_FRAGS(fa[(ks + 1) & 1], fb[(ks + 1) & 1], buf, ks + 1)
+#pragma unroll
+                    for (int i = 0; i < MB; ++i)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) acc[i][j] = MFMA_H16(fb[ks & 1][j], fa[ks & 1][i], acc[i][j]);
                 }
-                if (tt + 3 < n_tiles && !(PDBG(p) & 1)) {
-                    const int q3 = (tt + 3) / 9, tap3 = (tt + 3) - q3 * 9;
-                    DMA_B(buf, nt, q3, tap3)        // buffer of tile tt: free now
+                if (has_next) {
+                    // tile tt+1 was issued two tiles ago: let only tile tt+2's DMA stay in flight, then rendezvous
+                    if (tap < 7 || !last_chunk) {
+                        if (B_PER_WAVE == 6) WAIT_VM(6); else if (B_PER_WAVE == 5) WAIT_VM(5); else if (B_PER_WAVE == 4) WAIT_VM(4);
+                        else if (B_PER_WAVE == 3) WAIT_VM(3); else WAIT_VM(2);
+                    }
+                    else WAIT_VM(0);
+                    if (!(PDBG(p) & 8)) BARRIER();
+                    if (!same_chunk) {              // everyone is done with the old chunk's patch
+                        if (!(PDBG(p) & 2)) DMA_PATCH(q + 1)
+                        WAIT_VM(0);
+                        BARRIER();
+                    }
+                    if (!(PDBG(p) & 1)) {           // tile tt + 3 into the buffer of tile tt (free now)
+                        if (tap < 6) DMA_B(buf, nt, q, tap + 3)
+                        else if (!last_chunk) DMA_B(buf, nt, q + 1, tap - 6)
+                    }
                 }
+                (void)tt;
             }
-            buf = (buf == 2) ? 0 : buf + 1;
         }
 
         // ---- epilogue --------------------------------------------------------------------------
