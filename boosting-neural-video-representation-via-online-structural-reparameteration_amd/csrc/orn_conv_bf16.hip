@@ -562,13 +562,13 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p)
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][c][r] = 0.f;
-    // dbias rides along in the ti == 1 work-groups: dy^T x ones on the matrix core (wave-uniform branch)
-    f32x16 accb;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
-    h16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (h16)1.0f;
+    // dbias rides along: the A fragment holds 8 pixels of one dy channel per lane, so its column sum is four packed
+    // dot products with ones (v_dot2c_f32, fp32 accumulate) that issue under the MFMAs.  (A ones-MFMA in the ti == 1
+    // work-groups made those 11 % longer than their neighbours: -17 us on the last block's launch.)  Every work-group
+    // computes it -- no branch in the K loop -- and the ti == 1 ones store it.
+    float bsum = 0.f;
+    typedef __attribute__((ext_vector_type(2))) h16 h16v2;
+    const h16v2 ones2 = {(h16)1.0f, (h16)1.0f};
     const bool do_bias = (ti == 1);
 
     // per-lane transposed-read offsets (pixel part is added per K slice).  dy: this lane's pixels all have
@@ -632,7 +632,15 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p)
             for (int half = 0; half < 2; ++half) {
                 const unsigned char *ap = dys + (r * WB_TW + 16 * half) * WB_DYB + a_off;
                 const h16x8 a = tr_frag(ap, ap + 4 * WB_DYB);
-                if (do_bias) accb = MFMA_H16(a, ones, accb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const h16v2 a2 = {a[2 * e], a[2 * e + 1]};
+#ifdef ORN_FP16
+                    bsum = __builtin_amdgcn_fdot2(a2, ones2, bsum, false);
+#else
+                    bsum = __builtin_amdgcn_fdot2_f32_bf16(a2, ones2, bsum, false);
+#endif
+                }
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const unsigned char *bp = xs + (r * WB_XW + 16 * half + j) * WB_XB + b_off;
@@ -647,11 +655,8 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p)
     }
 #undef WDMA16
 #undef WDMA_TILE
-    if (do_bias && l31 == 0) {
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg)
-            p.bias_slabs[(size_t)sidx * O + o0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh] = accb[reg];
-    }
+    bsum += __shfl_xor(bsum, 32);                             // the two K halves of the row
+    if (do_bias && hh == 0) p.bias_slabs[(size_t)sidx * O + o0 + wave * 32 + l31] = bsum;
     float *out = p.slabs + (size_t)sidx * 9 * O * 96;
 #pragma unroll
     for (int j = 0; j < 3; ++j)
