@@ -42,6 +42,7 @@ struct orn_engine {
     int merge_tiles[4];
     int ff;                          // first layer on the bf16 fast path (== n_layers: none)
     float *dxn;                      // fp32 NHWC dgrad output of layer ff (converted to NCHW for the fp32 part)
+    bool stage0;                     // layer 0 is the only fp32 block and fits orn_stage0.hip: fused forward / backward
     // graph cache: one captured train step, and ORN_GRAPH_UNROLL steps back to back (the schedule is device-side, so
     // a longer graph is the same nodes repeated; it amortises the ~8 us gap between graph launches)
     hipGraph_t graph, graph_u;
@@ -140,6 +141,8 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
         if (i < ff) {
             L[i].z = take(asz); L[i].a = take(asz); L[i].da = take(asz);
             s1 = orn_conv3x3_ps_silu_bwd_ws_bytes(1, l.C, l.O, l.H, l.W) / 4;
+            const size_t s0 = (size_t)orn_stage0_slabs(l.O, l.s) * l.C * l.H * l.W;     // fused first block (orn_stage0.hip)
+            if (s0 > s1) s1 = s0;
         } else {
             // halfs are carved as floats (2 per float)
             const size_t wpz = (size_t)l.O * ORN_FAST_C * 9;
@@ -174,6 +177,8 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
         for (int i = 0; i < d->n_layers; ++i) e->L[i] = L[i];
         e->Hout = H; e->Wout = W; e->Cn_last = Cn;
         e->ff = ff; e->dxn = dxn;
+        const orn_layer_desc &l0 = d->layer[0];
+        e->stage0 = d->precision != 0 && ff == 1 && d->n_layers > 1 && orn_stage0_supported(l0.C, l0.O, l0.H, l0.W, l0.s);
         e->merge_tables = mtab;
         e->mh_tables = mhtab;
     }
@@ -335,11 +340,15 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
         LayerBuf &b = e->L[i];
         if (i < ff) {
             if (e->prof) (void)hipEventRecord(e->prof_ev[2 * i], st);
+            if (e->stage0)   // conv + PixelShuffle + SiLU straight into layer 1's 16-bit input (b.z in the fused pair's own layout)
+                ORN_TRY(orn_launch_stage0_fwd(x, b.wf, b.bf, l.C, l.O, l.H, l.W, l.s, keep_z ? b.z : nullptr, e->L[1].xpad, ORN_FAST_C,
+                                              d.precision, st));
+            else
             ORN_TRY(orn_launch_conv3x3_f32(x, b.wf, b.bf, 1, l.C, l.O, l.H, l.W, l.s, 1, keep_z ? b.z : nullptr, b.a, st, nullptr));
             if (e->prof) (void)hipEventRecord(e->prof_ev[2 * i + 1], st);
             x = b.a;
         } else {
-            if (i == ff) ORN_TRY(e->ops->to_nhwc(x, l.C, ORN_FAST_C, l.H, l.W, b.xpad, st));
+            if (i == ff && !e->stage0) ORN_TRY(e->ops->to_nhwc(x, l.C, ORN_FAST_C, l.H, l.W, b.xpad, st));
             if (e->prof) (void)hipEventRecord(e->prof_ev[2 * i], st);
             ORN_TRY(e->ops->conv_fwd(b.xpad, b.wb, b.biasp, l.H, l.W, ORN_FAST_C, l.O, l.s, b.zb, (i + 1 < nl) ? e->L[i + 1].xpad : nullptr, st));
             if (e->prof) (void)hipEventRecord(e->prof_ev[2 * i + 1], st);
@@ -397,9 +406,14 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
                                            part, st));
             } else {
                 ORN_TRY(e->ops->conv_dgrad(b.dypad, b.wd, l.H, l.W, l.O, ORN_FAST_C, nullptr, nullptr, 1, e->dxn, st));
+                if (!e->stage0)
                 ORN_TRY(e->ops->to_nchw_f32(e->dxn, l.C, ORN_FAST_C, l.H, l.W, e->ops->dgrad_f32_slabs(l.H, l.W, l.O), 1.0f / e->gs, dx,
                                             st));
             }
+        } else if (e->stage0) {
+            const orn_layer_desc &l1 = d.layer[1];
+            ORN_TRY(orn_launch_stage0_bwd(x, b.wf, b.z, e->dxn, e->ops->dgrad_f32_slabs(l1.H, l1.W, l1.O), ORN_FAST_C, 1.0f / e->gs, l.C, l.O,
+                                          l.H, l.W, l.s, e->scratch, dx, G + l.w3x3, G + l.b3x3, st));
         } else
         ORN_TRY(orn_launch_conv_bwd_f32(x, b.wf, b.z, b.da, 1, l.C, l.O, l.H, l.W, l.s, dx, G + l.w3x3, G + l.b3x3, e->scratch, st));
     }

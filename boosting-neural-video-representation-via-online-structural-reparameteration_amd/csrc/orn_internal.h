@@ -16,6 +16,14 @@ int orn_launch_head_bwd(const float *a, const float *w, const float *out, const 
 int orn_launch_adam(float *p, const float *g, float *m, float *v, size_t n, double lr, int step, const OrnStepCur *sp,
                     double beta1, double beta2, double eps, float inv_gscale, hipStream_t st, const float *gmask = nullptr);
 
+// orn_stage0.hip: the fp32 block below the first 16-bit one (tiny stem image), forward / backward as one launch each
+bool orn_stage0_supported(int C, int O, int H, int W, int s);
+int orn_stage0_slabs(int O, int s);
+int orn_launch_stage0_fwd(const float *x, const float *wf, const float *bf, int C, int O, int H, int W, int s, float *z,
+                          void *xpad_next, int Cp, int precision, hipStream_t st);
+int orn_launch_stage0_bwd(const float *x, const float *wf, const float *z, const float *dxn, int nslab, int Cp, float inv_gs, int C,
+                          int O, int H, int W, int s, float *slabs, float *dx, float *dwf, float *dbf, hipStream_t st);
+
 // orn_merge.hip
 int orn_launch_merge_fwd(const float *w3x3, const float *b3x3, const float *w3x1, const float *b3x1,
                          const float *w1x3, const float *b1x3, const float *w1, const float *w2, const float *w3,
