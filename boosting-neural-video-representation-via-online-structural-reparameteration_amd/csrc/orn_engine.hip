@@ -42,6 +42,7 @@ struct orn_engine {
     int merge_tiles[4];
     int ff;                          // first layer on the bf16 fast path (== n_layers: none)
     float *dxn;                      // fp32 NHWC dgrad output of layer ff (converted to NCHW for the fp32 part)
+    size_t stem_ws;                  // floats of `scratch` the stem backward uses (the fused first block's dx slabs sit behind them)
     bool stage0;                     // layer 0 is the only fp32 block and fits orn_stage0.hip: fused forward / backward
     // graph cache: one captured train step, and ORN_GRAPH_UNROLL steps back to back (the schedule is device-side, so
     // a longer graph is the same nodes repeated; it amortises the ~8 us gap between graph launches)
@@ -141,7 +142,7 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
         if (i < ff) {
             L[i].z = take(asz); L[i].a = take(asz); L[i].da = take(asz);
             s1 = orn_conv3x3_ps_silu_bwd_ws_bytes(1, l.C, l.O, l.H, l.W) / 4;
-            const size_t s0 = (size_t)orn_stage0_slabs(l.O, l.s) * l.C * l.H * l.W;     // fused first block (orn_stage0.hip)
+            const size_t s0 = al(orn_stem_bwd_ws_floats(1, d->stem_dim, Nout)) + (size_t)orn_stage0_slabs(l.O, l.s) * l.C * l.H * l.W;   // fused first block
             if (s0 > s1) s1 = s0;
         } else {
             // halfs are carved as floats (2 per float)
@@ -177,6 +178,7 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
         for (int i = 0; i < d->n_layers; ++i) e->L[i] = L[i];
         e->Hout = H; e->Wout = W; e->Cn_last = Cn;
         e->ff = ff; e->dxn = dxn;
+        e->stem_ws = al(orn_stem_bwd_ws_floats(1, d->stem_dim, Nout));
         const orn_layer_desc &l0 = d->layer[0];
         e->stage0 = d->precision != 0 && ff == 1 && d->n_layers > 1 && orn_stage0_supported(l0.C, l0.O, l0.H, l0.W, l0.s);
         e->merge_tables = mtab;
@@ -413,7 +415,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         } else if (e->stage0) {
             const orn_layer_desc &l1 = d.layer[1];
             ORN_TRY(orn_launch_stage0_bwd(x, b.wf, b.z, e->dxn, e->ops->dgrad_f32_slabs(l1.H, l1.W, l1.O), ORN_FAST_C, 1.0f / e->gs, l.C, l.O,
-                                          l.H, l.W, l.s, e->scratch, dx, G + l.w3x3, G + l.b3x3, st));
+                                          l.H, l.W, l.s, e->scratch + e->stem_ws, nullptr, G + l.w3x3, G + l.b3x3, st));
         } else
         ORN_TRY(orn_launch_conv_bwd_f32(x, b.wf, b.z, b.da, 1, l.C, l.O, l.H, l.W, l.s, dx, G + l.w3x3, G + l.b3x3, e->scratch, st));
     }
@@ -437,8 +439,11 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         }
         ORN_TRY(orn_launch_merge_bwd_tail_all(nl, mm, st));
     }
-    ORN_TRY(orn_launch_stem_bwd(embeds, fidx, d.embed_len, P + d.stem_w1, e->pre1, e->h1, e->pre2, e->dh2, 1, d.embed_len,
-                                d.stem_dim, Nout, G + d.stem_w0, G + d.stem_b0, G + d.stem_w1, G + d.stem_b1, e->scratch, st));
+    // fused first block: dh2 arrives as its per-work-group partial rows (behind the stem's own scratch), summed by the stem kernel
+    ORN_TRY(orn_launch_stem_bwd(embeds, fidx, d.embed_len, P + d.stem_w1, e->pre1, e->h1, e->pre2,
+                                e->stage0 ? e->scratch + e->stem_ws : e->dh2, 1, d.embed_len, d.stem_dim, Nout, G + d.stem_w0,
+                                G + d.stem_b0, G + d.stem_w1, G + d.stem_b1, e->scratch, st,
+                                e->stage0 ? orn_stage0_slabs(d.layer[0].O, d.layer[0].s) : 1));
     ORN_TRY(orn_launch_adam(P, G, e->m, e->v, (size_t)d.n_params, 0.0, 1, e->cur, d.beta1, d.beta2, d.eps, 1.0f, st, e->gmask));
     return 0;
 }

@@ -7,7 +7,8 @@ int orn_launch_linear_silu(const float *x, const int *row_idx, size_t row_stride
                            int B, int K, int N, float *pre, float *y, hipStream_t st);
 int orn_launch_stem_bwd(const float *embed, const int *row_idx, size_t row_stride, const float *w1, const float *pre1,
                         const float *h1, const float *pre2, const float *dh2, int B, int E, int Hd, int Nout,
-                        float *dw0, float *db0, float *dw1, float *db1, float *ws, hipStream_t st);
+                        float *dw0, float *db0, float *dw1, float *db1, float *ws, hipStream_t st, int dh2_nslab = 1);
+// dh2_nslab > 1 (B == 1): dh2 holds that many partial rows of Nout floats, summed in fixed order by the first kernel
 size_t orn_stem_bwd_ws_floats(int B, int Hd, int Nout);
 int orn_launch_head_fwd(const float *a, const float *w, const float *b, int B, int C, size_t HW, int sigmoid,
                         float *out, hipStream_t st);

@@ -356,19 +356,21 @@ int orn_launch_stage0_fwd(const float *x, const float *wf, const float *bf, int 
 }
 
 // dxn: the next block's fp32 dgrad slabs [nslab][H*s][W*s][Cp] (times 1/inv_gs); z: what orn_launch_stage0_fwd kept;
-// slabs: orn_stage0_slabs(O, s) * C*H*W floats of scratch; dx [C][H][W], dwf, dbf are overwritten.
+// slabs: orn_stage0_slabs(O, s) * C*H*W floats of scratch; dx [C][H][W] (null: leave the slabs to the caller), dwf, dbf
+// are overwritten.
 int orn_launch_stage0_bwd(const float *x, const float *wf, const float *z, const float *dxn, int nslab, int Cp, float inv_gs, int C,
                           int O, int H, int W, int s, float *slabs, float *dx, float *dwf, float *dbf, hipStream_t st)
 {
     Stage0P p;
     ORN_TRY(fill(p, x, wf, nullptr, C, O, H, W, s));
-    ORN_REQUIRE(z && dxn && nslab >= 1 && slabs && dx && dwf && dbf, "stage0_bwd: null pointer");
+    ORN_REQUIRE(z && dxn && nslab >= 1 && slabs && dwf && dbf, "stage0_bwd: null pointer");
     p.z = const_cast<float *>(z); p.dxn = dxn; p.nslab = nslab; p.Cp = Cp; p.inv_gs = inv_gs; p.dwf = dwf; p.dbf = dbf; p.dx_slabs = slabs;
     const size_t smem = smem_bytes(p.C4, p.C16, H, W, true);
     ORN_TRY(set_smem(k_stage0_bwd, smem));
     const int nwg = orn_stage0_slabs(O, s);
     hipLaunchKernelGGL(k_stage0_bwd, dim3(nwg), dim3(orn_cdiv(H * W, 16) * 64), smem, st, p);
     ORN_LAUNCH_CHECK("stage0_bwd");
+    if (!dx) return 0;                 // the consumer (orn_launch_stem_bwd with dh2_nslab) sums the slabs itself
     const size_t n = (size_t)C * H * W;
     return orn_launch_reduce_rows(slabs, nwg, n, n, dx, st);
 }
