@@ -671,8 +671,8 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p)
 
 // dWf[o][c][i][j] = gscale * sum_s slabs[s][tap][o'(o)][c],  o' = (o % s2)*Cn + o / s2
 // Cr <= 96 real input channels (a narrower first fast layer runs zero-padded to 96): only those are written
-__global__ void k_wgrad_bf16_reduce(const float *__restrict__ slabs, const float *__restrict__ bias_slabs, int S, int O, int Cn,
-                                    int s2, int Cr, float gscale, float *__restrict__ dwf, float *__restrict__ dbf)
+__device__ __forceinline__ void wgrad_reduce_body(const float *__restrict__ slabs, const float *__restrict__ bias_slabs, int S, int O, int Cn,
+                                                  int s2, int Cr, float gscale, float *__restrict__ dwf, float *__restrict__ dbf)
 {
     const size_t n = (size_t)9 * O * 96;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -699,6 +699,24 @@ __global__ void k_wgrad_bf16_reduce(const float *__restrict__ slabs, const float
     const int ij = op / Cn, nn = op - ij * Cn;
     const int o = nn * s2 + ij;
     dwf[((size_t)o * Cr + c) * 9 + tap] = acc * gscale;
+}
+
+__global__ void k_wgrad_bf16_reduce(const float *__restrict__ slabs, const float *__restrict__ bias_slabs, int S, int O, int Cn,
+                                    int s2, int Cr, float gscale, float *__restrict__ dwf, float *__restrict__ dbf)
+{
+    wgrad_reduce_body(slabs, bias_slabs, S, O, Cn, s2, Cr, gscale, dwf, dbf);
+}
+
+// Every fast layer's reduction in one launch at the end of the backward (blockIdx.y = layer): four graph nodes of 6-26 us
+// that each started cold become one that keeps the whole chip streaming.
+struct WgradReduceAll {
+    struct { const float *slabs, *bias_slabs; int S, O, Cn, s2, Cr; float gscale; float *dwf, *dbf; } l[ORN_MAX_LAYERS];
+};
+__global__ void k_wgrad_bf16_reduce_all(WgradReduceAll a)
+{
+    const auto &l = a.l[blockIdx.y];
+    if ((size_t)blockIdx.x * blockDim.x >= (size_t)9 * l.O * 96) return;
+    wgrad_reduce_body(l.slabs, l.bias_slabs, l.S, l.O, l.Cn, l.s2, l.Cr, l.gscale, l.dwf, l.dbf);
 }
 
 int orn_wgrad_bf16_split(int H, int W, int O)
@@ -742,10 +760,30 @@ int orn_launch_wgrad_bf16(const h16 *xpad, const h16 *dypad, int H, int W, int C
     }
     hipLaunchKernelGGL(k_wgrad_nhwc_bf16, dim3(3 * p.n_otiles * p.S), dim3(256), smem, st, p);
     ORN_LAUNCH_CHECK("wgrad_nhwc_bf16");
+    if (!dwf) return 0;                 // deferred: orn_launch_wgrad_reduce_all
     const size_t n = (size_t)9 * O * 96;
     hipLaunchKernelGGL(k_wgrad_bf16_reduce, dim3(orn_cdiv((long)n, 256)), dim3(256), 0, st, slabs, p.bias_slabs, p.S, O,
                        O / (s * s), s * s, C, gscale, dwf, dbf);
     ORN_LAUNCH_CHECK("wgrad_bf16_reduce");
+    return 0;
+}
+
+int orn_launch_wgrad_reduce_all(int n, const OrnWgradReduce *L, hipStream_t st)
+{
+    if (n == 0) return 0;
+    ORN_REQUIRE(n <= ORN_MAX_LAYERS, "wgrad_reduce_all: %d layers", n);
+    WgradReduceAll a;
+    size_t mx = 0;
+    for (int i = 0; i < n; ++i) {
+        const int S = orn_wgrad_bf16_split(L[i].H, L[i].W, L[i].O), s2 = L[i].s * L[i].s;
+        a.l[i].slabs = L[i].slabs; a.l[i].bias_slabs = L[i].slabs + (size_t)S * 9 * L[i].O * 96;
+        a.l[i].S = S; a.l[i].O = L[i].O; a.l[i].Cn = L[i].O / s2; a.l[i].s2 = s2; a.l[i].Cr = L[i].C; a.l[i].gscale = L[i].gscale;
+        a.l[i].dwf = L[i].dwf; a.l[i].dbf = L[i].dbf;
+        const size_t w = (size_t)9 * L[i].O * 96;
+        if (w > mx) mx = w;
+    }
+    hipLaunchKernelGGL(k_wgrad_bf16_reduce_all, dim3(orn_cdiv((long)mx, 256), n), dim3(256), 0, st, a);
+    ORN_LAUNCH_CHECK("wgrad_bf16_reduce_all");
     return 0;
 }
 
@@ -1196,7 +1234,7 @@ static int a_head_bwd(const void *z, const float *w, const float *out, const flo
                       float gs_up, void *dypad, float *dw, float *db, float *ws, hipStream_t st)
 { return orn_launch_head_bwd_bf16((const h16 *)z, w, out, dout, C, H, W, sigmoid, sp, gs_up, (h16 *)dypad, dw, db, ws, st); }
 
-const OrnHalfOps ops = {a_conv_fwd, a_conv_dgrad, orn_wgrad_bf16_ws_floats, a_wgrad, orn_launch_prep_weights_bf16_all, a_to_nhwc,
+const OrnHalfOps ops = {a_conv_fwd, a_conv_dgrad, orn_wgrad_bf16_ws_floats, a_wgrad, orn_launch_wgrad_reduce_all, orn_launch_prep_weights_bf16_all, a_to_nhwc,
                         orn_launch_nhwc_to_nchw_f32, orn_dgrad_f32_slabs, a_head_fwd, orn_head_bwd_bf16_ws_floats, a_head_bwd};
 
 #ifndef ORN_FP16

@@ -20,6 +20,7 @@ struct LayerBuf {
     uint16_t *dypad;      // gradient wrt conv output, zero-bordered [H+2][W+2][O']
     uint16_t *wb, *wd;    // merged kernel in 16 bit: forward / dgrad operand layouts
     float *biasp;         // bias in o' order
+    float *wslab;         // split-K slabs of this layer's wgrad (reduced for all layers at the end of the backward)
 };
 
 struct orn_engine {
@@ -153,6 +154,7 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
             L[i].wb = (uint16_t *)take((wpz + 1) / 2);
             L[i].wd = (uint16_t *)take((wpz + 1) / 2);
             L[i].biasp = take(l.O);
+            L[i].wslab = take(orn_half_ops_bf16()->wgrad_ws_floats(l.H, l.W, l.O));
             const OrnHalfOps *ops = orn_half_ops_bf16();     // sizes do not depend on the element type
             if (i == ff) dxn = take((size_t)l.H * l.W * ORN_FAST_C * ops->dgrad_f32_slabs(l.H, l.W, l.O));
             s1 = al(ops->wgrad_ws_floats(l.H, l.W, l.O));
@@ -400,7 +402,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         float *dx = (i == 0) ? e->dh2 : e->L[i - 1].da;
         // dWf / dbf land directly in the 3x3 branch's gradient slots (dW3x3 = dWf, db3x3 = dbf)
         if (i >= ff) {
-            ORN_TRY(e->ops->wgrad(b.xpad, b.dypad, l.H, l.W, l.C, l.O, l.s, 1.0f / e->gs, e->scratch, G + l.w3x3, G + l.b3x3, st));
+            ORN_TRY(e->ops->wgrad(b.xpad, b.dypad, l.H, l.W, l.C, l.O, l.s, 1.0f / e->gs, b.wslab, nullptr, nullptr, st));
             if (i > ff) {
                 // few pixel tiles: input-chunk split through fp32 partial slabs in the scratch, finished into dypad
                 float *part = e->ops->dgrad_f32_slabs(l.H, l.W, l.O) > 1 ? e->scratch : nullptr;
@@ -418,6 +420,14 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
                                           l.H, l.W, l.s, e->scratch + e->stem_ws, nullptr, G + l.w3x3, G + l.b3x3, st));
         } else
         ORN_TRY(orn_launch_conv_bwd_f32(x, b.wf, b.z, b.da, 1, l.C, l.O, l.H, l.W, l.s, dx, G + l.w3x3, G + l.b3x3, e->scratch, st));
+    }
+    if (ff < nl) {      // dWf / dbf of every fast layer from its split-K slabs, one launch
+        OrnWgradReduce wr[ORN_MAX_LAYERS];
+        for (int i = ff; i < nl; ++i) {
+            const orn_layer_desc &l = d.layer[i];
+            wr[i - ff] = OrnWgradReduce{e->L[i].wslab, l.H, l.W, l.C, l.O, l.s, 1.0f / e->gs, G + l.w3x3, G + l.b3x3};
+        }
+        ORN_TRY(e->ops->wgrad_reduce_all(nl - ff, wr, st));
     }
     if (d.erb) {
         // merge backward of every layer (closed forms): dW3 & dT, then dW2 & dW1, then the slices
