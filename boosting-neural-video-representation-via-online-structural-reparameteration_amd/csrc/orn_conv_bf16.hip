@@ -540,7 +540,7 @@ __device__ __forceinline__ h16x8 tr_frag(const unsigned char *base0, const unsig
 
 // Both LDS images are filled by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction) into a 2-deep ring:
 // tile t+1 streams in while tile t feeds the matrix core; one barrier per tile; two work-groups per CU.
-__global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p)
+__device__ __forceinline__ void wgrad_body(const WgradBP &p, const int id)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -548,7 +548,6 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p)
     const int l31 = lane & 31, hh = lane >> 5;
     const int g = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
     // XCD-aware decode: the 9 work-groups that share one pixel range sit on one XCD (speed only)
-    const int id = blockIdx.x;
     const int xcd = id & 7, qx = id >> 3;
     const int sub = qx % (3 * p.n_otiles), sidx = (qx / (3 * p.n_otiles)) * 8 + xcd;
     const int ti = sub % 3, ot = sub / 3;
@@ -669,6 +668,20 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p)
             }
 }
 
+__global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p) { wgrad_body(p, blockIdx.x); }
+
+// Several layers in one launch (problems in the order given, each on a multiple-of-8 block range so the XCD decode holds):
+// the small layers' wgrads do not fill the chip one at a time (72 / 216 / 360 work-groups for 512 slots at 720p), and
+// nothing but the deferred reduction consumes them.
+struct WgradBPAll { int n; int start[ORN_MAX_LAYERS + 1]; WgradBP p[ORN_MAX_LAYERS]; };
+__global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16_all(WgradBPAll a)
+{
+    int k = 0;
+    while (k + 1 < a.n && (int)blockIdx.x >= a.start[k + 1]) ++k;
+    k = __builtin_amdgcn_readfirstlane(k);
+    wgrad_body(a.p[k], (int)blockIdx.x - a.start[k]);
+}
+
 // dWf[o][c][i][j] = gscale * sum_s slabs[s][tap][o'(o)][c],  o' = (o % s2)*Cn + o / s2
 // Cr <= 96 real input channels (a narrower first fast layer runs zero-padded to 96): only those are written
 __device__ __forceinline__ void wgrad_reduce_body(const float *__restrict__ slabs, const float *__restrict__ bias_slabs, int S, int O, int Cn,
@@ -739,11 +752,9 @@ size_t orn_wgrad_bf16_ws_floats(int H, int W, int O) { return (size_t)orn_wgrad_
 
 // dwf [O][C][3][3] and dbf [O] (PyTorch channel order), both overwritten.  C <= 96 real channels; xpad always has 96
 // channels per pixel (zeros above C).
-int orn_launch_wgrad_bf16(const h16 *xpad, const h16 *dypad, int H, int W, int C, int O, int s, float gscale,
-                          float *slabs, float *dwf, float *dbf, hipStream_t st)
+static int wgrad_fill(WgradBP &p, const h16 *xpad, const h16 *dypad, int H, int W, int C, int O, int s, float *slabs)
 {
     ORN_REQUIRE(C >= 1 && C <= 96 && O % WB_BO == 0 && O % (s * s) == 0, "wgrad_bf16: unsupported C=%d O=%d", C, O);
-    WgradBP p;
     p.dbg = g_conv_dbg;
     p.xpad = xpad; p.dypad = dypad; p.slabs = slabs; p.H = H; p.W = W; p.O = O;
     p.tiles_w = orn_cdiv(W, WB_TW);
@@ -752,13 +763,43 @@ int orn_launch_wgrad_bf16(const h16 *xpad, const h16 *dypad, int H, int W, int C
     p.bias_slabs = slabs + (size_t)p.S * 9 * O * 96;
     p.n_otiles = O / WB_BO;
     static bool attr_done = false;
-    const size_t smem = 2 * WB_BUF_BYTES;
     if (!attr_done) {
+        const size_t smem = 2 * WB_BUF_BYTES;
         hipError_t e = hipFuncSetAttribute((const void *)k_wgrad_nhwc_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_wgrad_nhwc_bf16_all, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) { orn_set_error("wgrad_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
-    hipLaunchKernelGGL(k_wgrad_nhwc_bf16, dim3(3 * p.n_otiles * p.S), dim3(256), smem, st, p);
+    return 0;
+}
+
+// slabs only (no reduction), several layers in one launch
+int orn_launch_wgrad_bf16_batch(int n, const OrnWgradJob *J, hipStream_t st)
+{
+    if (n == 0) return 0;
+    ORN_REQUIRE(n <= ORN_MAX_LAYERS, "wgrad_batch: %d layers", n);
+    WgradBPAll a;
+    a.n = n;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        ORN_TRY(wgrad_fill(a.p[i], (const h16 *)J[i].xpad, (const h16 *)J[i].dypad, J[i].H, J[i].W, J[i].C, J[i].O, J[i].s, J[i].slabs));
+        a.start[i] = total;
+        total += 3 * a.p[i].n_otiles * a.p[i].S;        // S % 8 == 0: every start is a multiple of 8
+    }
+    a.start[n] = total;
+    hipLaunchKernelGGL(k_wgrad_nhwc_bf16_all, dim3(total), dim3(256), 2 * WB_BUF_BYTES, st, a);
+    ORN_LAUNCH_CHECK("wgrad_nhwc_bf16_all");
+    return 0;
+}
+
+// dwf [O][C][3][3] and dbf [O] (PyTorch channel order), both overwritten.  C <= 96 real channels; xpad always has 96
+// channels per pixel (zeros above C).
+int orn_launch_wgrad_bf16(const h16 *xpad, const h16 *dypad, int H, int W, int C, int O, int s, float gscale,
+                          float *slabs, float *dwf, float *dbf, hipStream_t st)
+{
+    WgradBP p;
+    ORN_TRY(wgrad_fill(p, xpad, dypad, H, W, C, O, s, slabs));
+    hipLaunchKernelGGL(k_wgrad_nhwc_bf16, dim3(3 * p.n_otiles * p.S), dim3(256), 2 * WB_BUF_BYTES, st, p);
     ORN_LAUNCH_CHECK("wgrad_nhwc_bf16");
     if (!dwf) return 0;                 // deferred: orn_launch_wgrad_reduce_all
     const size_t n = (size_t)9 * O * 96;
@@ -1234,7 +1275,7 @@ static int a_head_bwd(const void *z, const float *w, const float *out, const flo
                       float gs_up, void *dypad, float *dw, float *db, float *ws, hipStream_t st)
 { return orn_launch_head_bwd_bf16((const h16 *)z, w, out, dout, C, H, W, sigmoid, sp, gs_up, (h16 *)dypad, dw, db, ws, st); }
 
-const OrnHalfOps ops = {a_conv_fwd, a_conv_dgrad, orn_wgrad_bf16_ws_floats, a_wgrad, orn_launch_wgrad_reduce_all, orn_launch_prep_weights_bf16_all, a_to_nhwc,
+const OrnHalfOps ops = {a_conv_fwd, a_conv_dgrad, orn_wgrad_bf16_ws_floats, a_wgrad, orn_launch_wgrad_bf16_batch, orn_launch_wgrad_reduce_all, orn_launch_prep_weights_bf16_all, a_to_nhwc,
                         orn_launch_nhwc_to_nchw_f32, orn_dgrad_f32_slabs, a_head_fwd, orn_head_bwd_bf16_ws_floats, a_head_bwd};
 
 #ifndef ORN_FP16

@@ -86,6 +86,7 @@ int orn_launch_loss(const float *pred, const float *target, const int *frame_idx
 struct OrnPrepLayer { const float *wf, *bf; int O, C, s; void *wb, *wd; float *biasp; int Cp; };   // Cp: channel stride (0: = C)
 // deferred split-K reduction of a layer's wgrad slabs (wgrad called with dwf == nullptr leaves them in `slabs`)
 struct OrnWgradReduce { const float *slabs; int H, W, C, O, s; float gscale; float *dwf, *dbf; };
+struct OrnWgradJob { const void *xpad, *dypad; int H, W, C, O, s; float *slabs; };   // wgrad into slabs, reduction deferred
 struct OrnHalfOps {
     int (*conv_fwd)(const void *xpad, const void *wb, const float *bias_p, int H, int W, int Cin, int O, int s, void *z, void *apad,
                     hipStream_t st);
@@ -94,6 +95,7 @@ struct OrnHalfOps {
     size_t (*wgrad_ws_floats)(int H, int W, int O);
     int (*wgrad)(const void *xpad, const void *dypad, int H, int W, int C, int O, int s, float gscale, float *slabs, float *dwf,
                  float *dbf, hipStream_t st);
+    int (*wgrad_batch)(int n, const OrnWgradJob *J, hipStream_t st);           // several layers' slabs in one launch
     int (*wgrad_reduce_all)(int n, const OrnWgradReduce *L, hipStream_t st);   // all layers' reductions in one launch
     int (*prep_all)(int n, const OrnPrepLayer *L, hipStream_t st);
     int (*to_nhwc)(const float *src, int C, int Cp, int H, int W, void *dst, hipStream_t st);
