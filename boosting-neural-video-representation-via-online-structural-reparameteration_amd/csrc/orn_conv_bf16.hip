@@ -107,9 +107,17 @@ struct ConvBP {
     int dbg;             // timing-only ablation flags (tools/probes): 1 no weight restage, 2 no patch stage, 4 no stores
 };
 
-template <int WAVES_M, int WAVES_N, int MB, int NB, int EPI>
+// CK = input channels per K chunk: 96 (the general form above), or 32 for a layer whose input has <= 32 real channels
+// (the zero-padded narrow layer, forward only): its whole K = 9 x 32 fits LDS -- patch 22 KB + all nine [BN][32] weight
+// tiles 72 KB -- so an N tile is ONE rendezvous and 72 back-to-back MFMAs per wave instead of nine rounds of barrier +
+// counted wait + 24 MFMAs of which two thirds multiply zeros.  Rows are 64 B: 4 chunks, XOR swizzle (chunk ^ ((row >> 2) & 3)).
+template <int WAVES_M, int WAVES_N, int MB, int NB, int EPI, int CK = CB_CK>
 __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP p)
 {
+    constexpr bool NARROW = (CK != CB_CK);
+    static_assert(CK == CB_CK || (CK == 32 && EPI_IS_FWD(EPI)), "narrow form: 32 channels, forward only");
+    constexpr int NCH = CK / 8;                        // 16-byte chunks per LDS row
+    constexpr int NBUF = NARROW ? 9 : 3;               // weight tiles resident at once
     constexpr int NT = WAVES_M * WAVES_N * 64;
     constexpr int BN = WAVES_N * NB * 32;
     static_assert(WAVES_M * MB == CB_TH, "M tile must be 8 rows of 32 pixels");
@@ -119,13 +127,14 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
     // per-lane SOURCE address and on the fragment reads (both sides or neither: guide rule 21).
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NWAVES = WAVES_M * WAVES_N;
-    constexpr int ROWB = 192;
-    constexpr int PATCH_LDS = 65536;                   // 340 pixels x 192 B = 65,280 -> 64 wave-instructions
+    constexpr int ROWB = CK * 2;
+    constexpr int PATCH_INSTR = (CB_PH * CB_PW * ROWB + 1023) / 1024;   // 340 pixels x 192 B = 65,280 -> 64 wave-instructions
+    constexpr int PATCH_LDS = PATCH_INSTR * 1024;
     constexpr int BS_BYTES = BN * ROWB;
     constexpr int B_INSTR = BS_BYTES / 1024;           // wave-instructions per weight tile
     constexpr int B_PER_WAVE = (B_INSTR + NWAVES - 1) / NWAVES;
-    constexpr int P_PER_WAVE = 64 / NWAVES;
-    static_assert(64 % NWAVES == 0 && BS_BYTES % 1024 == 0, "tile geometry");
+    constexpr int P_PER_WAVE = (PATCH_INSTR + NWAVES - 1) / NWAVES;
+    static_assert((NARROW || PATCH_INSTR % NWAVES == 0) && BS_BYTES % 1024 == 0, "tile geometry");
     unsigned char *patch = smem;
     unsigned char *bs0 = smem + PATCH_LDS;
 
@@ -145,7 +154,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
     const int h0 = th * CB_TH, w0 = tw * CB_TW;
     const int H = p.H, W = p.W, Cin = p.Cin;
     const int q_base = (EPI == EPI_B_DGRAD_F32 && p.qsplit) ? (int)blockIdx.y : 0;   // chunk split: this WG's chunk
-    const int Q = (EPI == EPI_B_DGRAD_F32 && p.qsplit) ? 1 : Cin / CB_CK;
+    const int Q = (NARROW || (EPI == EPI_B_DGRAD_F32 && p.qsplit)) ? 1 : Cin / CB_CK;
     if (EPI == EPI_B_DGRAD_F32 && p.qsplit) nt0 = 0;
     const int n_tiles = Q * 9;                         // weight tiles per N tile
 
@@ -156,15 +165,15 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
 #pragma unroll
     for (int k = 0; k < B_PER_WAVE; ++k) {
         const int m = (uwave + NWAVES * k) % B_INSTR;              // surplus instructions re-load a tile piece (harmless)
-        const int L = m * 64 + lane, R = L / 12, pos = L - R * 12;
-        const int c = (pos - ((R >> 2) & 3) + 12) % 12;
+        const int L = m * 64 + lane, R = L / NCH, pos = L - R * NCH;
+        const int c = NARROW ? (pos ^ ((R >> 2) & 3)) : (pos - ((R >> 2) & 3) + 12) % 12;
         b_goff[k] = R * Cin + c * 8;
     }
 #pragma unroll
     for (int k = 0; k < P_PER_WAVE; ++k) {
         const int m = uwave + NWAVES * k;
-        const int L = m * 64 + lane, pix = L / 12, pos = L - pix * 12;
-        const int c = (pos - ((pix >> 2) & 3) + 12) % 12;
+        const int L = m * 64 + lane, pix = L / NCH, pos = L - pix * NCH;
+        const int c = NARROW ? (pos ^ ((pix >> 2) & 3)) : (pos - ((pix >> 2) & 3) + 12) % 12;
         const int pr = pix / CB_PW, pc = pix - pr * CB_PW;
         const int gh = h0 + pr, gw_ = w0 + pc;
         p_ok[k] = (pix < CB_PH * CB_PW) && gh < H + 2 && gw_ < W + 2;
@@ -176,32 +185,31 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
                                      (__attribute__((address_space(3))) void *)(smem + (ldsoff_)), 16, 0, 0)
 #define DMA_B(buf_, nt_, q_, tap_)                                                                              \
     {                                                                                                           \
-        const h16 *wbase = p.w + ((size_t)((tap_) * p.Nout + (nt_) * BN) * Cin + ((q_) + q_base) * CB_CK);      \
+        const h16 *wbase = p.w + ((size_t)((tap_) * p.Nout + (nt_) * BN) * Cin + ((q_) + q_base) * CK);         \
         _Pragma("unroll") for (int k = 0; k < B_PER_WAVE; ++k)                                                  \
             DMA16(wbase + b_goff[k], PATCH_LDS + (buf_) * BS_BYTES + ((uwave + NWAVES * k) % B_INSTR) * 1024);  \
     }
 #define DMA_PATCH(q_)                                                                                           \
     {                                                                                                           \
         _Pragma("unroll") for (int k = 0; k < P_PER_WAVE; ++k)                                                  \
-            DMA16(p.xpad + p_goff[k] + (p_ok[k] ? ((q_) + q_base) * CB_CK : 0), (uwave + NWAVES * k) * 1024);   \
+            if (!NARROW || uwave + NWAVES * k < PATCH_INSTR)                                                    \
+                DMA16(p.xpad + p_goff[k] + (p_ok[k] ? ((q_) + q_base) * CK : 0), (uwave + NWAVES * k) * 1024);  \
     }
 #define WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory")
 #define BARRIER() __builtin_amdgcn_s_barrier()
     // fragment reads: 16 bytes at logical chunk (2*ks + hh) of a row -> rotated position
+#define CHUNK_OFF(rot_, ks_) (NARROW ? 16 * ((2 * (ks_) + hh) ^ (rot_)) : wrap_row(16 * (hh + (rot_)) + (ks_) * 32))
 #define READ_FRAGS(A_, B_, buf_, ks_)                                                                           \
     {                                                                                                           \
-        _Pragma("unroll") for (int i = 0; i < MB; ++i) {                                                        \
-            int o = a_pos[i] + (ks_) * 32;                                                                      \
-            o -= (o >= ROWB) ? ROWB : 0;                                                                        \
-            A_[i] = *reinterpret_cast<const h16x8 *>(patch + a_row[i] + o);                                     \
-        }                                                                                                       \
-        int ob = b_pos + (ks_) * 32;                                                                            \
-        ob -= (ob >= ROWB) ? ROWB : 0;                                                                          \
+        _Pragma("unroll") for (int i = 0; i < MB; ++i)                                                          \
+            A_[i] = *reinterpret_cast<const h16x8 *>(patch + a_row[i] + CHUNK_OFF(a_rot[i], ks_));              \
+        const int ob = CHUNK_OFF(b_rot, ks_);                                                                   \
         _Pragma("unroll") for (int j = 0; j < NB; ++j)                                                          \
             B_[j] = *reinterpret_cast<const h16x8 *>(bs0 + (buf_) * BS_BYTES + b_row + j * 32 * ROWB + ob);     \
     }
+    auto wrap_row = [](int o) { return o - ((o >= ROWB) ? ROWB : 0); };
     const int b_row = (wn * NB * 32 + l31) * ROWB;
-    const int b_pos = 16 * (hh + ((l31 >> 2) & 3));
+    const int b_rot = (l31 >> 2) & 3;
 
     // EPI_B_FWD: the packed outputs of an N tile are stored AFTER the next N tile's prologue rendezvous, so the
     // store drain overlaps the next main loop instead of stalling the prologue's vmcnt(0)
@@ -221,7 +229,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
         }                                                                                                       \
         pending = false;                                                                                        \
     }
-    float *sbias = reinterpret_cast<float *>(smem + PATCH_LDS + 3 * BS_BYTES);     // [Nout] after the weight ring (EPI_B_FWD)
+    float *sbias = reinterpret_cast<float *>(smem + PATCH_LDS + NBUF * BS_BYTES);     // [Nout] after the weight ring (EPI_B_FWD)
     if (EPI_IS_FWD(EPI))
         for (int i = t; i < p.Nout; i += NT) sbias[i] = p.bias ? p.bias[i] : 0.f;   // visible after the first N tile's barriers
     for (int nti = 0; nti < nt_cnt; ++nti) {
@@ -242,9 +250,13 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
         if ((nti == 0 || Q > 1) && !(PDBG(p) & 2)) DMA_PATCH(0)
         DMA_B(0, nt, 0, 0)
         if (n_tiles > 1) DMA_B(1, nt, 0, 1)
+        if (NARROW) {                                  // the whole K of this N tile: taps 2..8 too, then the only rendezvous
+#pragma unroll
+            for (int tp = 2; tp < 9; ++tp) DMA_B(tp, nt, 0, tp)
+        }
         WAIT_VM(0);
         BARRIER();
-        if (n_tiles > 2) DMA_B(2, nt, 0, 2)
+        if (!NARROW && n_tiles > 2) DMA_B(2, nt, 0, 2)
         if (EPI_IS_FWD(EPI) && pending) FLUSH_DEFERRED()
         h16x8 fa[2][MB], fb[2][NB];
         // Chunks of 96 input channels outside, the nine taps inside and fully unrolled: tap, kernel row / column and the
@@ -254,28 +266,28 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
             for (int tap = 0; tap < 9; ++tap) {
                 const int tt = q * 9 + tap;
                 constexpr int dummy_ = 0; (void)dummy_;
-                const int buf = tap % 3;
+                const int buf = NARROW ? tap : tap % 3;
                 const int ti = tap / 3, tj = tap - ti * 3;
                 const bool last_chunk = (q + 1 >= Q);
                 const bool has_next = (tap < 8) || !last_chunk;
                 const bool same_chunk = (tap < 8);
-                int a_row[MB], a_pos[MB];
+                int a_row[MB], a_rot[MB];
 #pragma unroll
                 for (int i = 0; i < MB; ++i) {
                     const int pix = (wm * MB + i + ti) * CB_PW + l31 + tj;
                     a_row[i] = pix * ROWB;
-                    a_pos[i] = 16 * (hh + ((pix >> 2) & 3));
+                    a_rot[i] = (pix >> 2) & 3;
                 }
                 READ_FRAGS(fa[0], fb[0], buf, 0)
 #pragma unroll
-                for (int ks = 0; ks < CB_CK / 16; ++ks) {
-                    if (ks + 1 < CB_CK / 16 && !(PDBG(p) & 16)) READ_FRAGS(fa[(ks + 1) & 1], fb[(ks + 1) & 1], buf, ks + 1)
+                for (int ks = 0; ks < CK / 16; ++ks) {
+                    if (ks + 1 < CK / 16 && !(PDBG(p) & 16)) READ_FRAGS(fa[(ks + 1) & 1], fb[(ks + 1) & 1], buf, ks + 1)
 #pragma unroll
                     for (int i = 0; i < MB; ++i)
 #pragma unroll
                         for (int j = 0; j < NB; ++j) acc[i][j] = MFMA_H16(fb[ks & 1][j], fa[ks & 1][i], acc[i][j]);
                 }
-                if (has_next) {
+                if (!NARROW && has_next) {
                     // tile tt+1 was issued two tiles ago: let only tile tt+2's DMA stay in flight, then rendezvous
                     if (tap < 7 || !last_chunk) {
                         if (B_PER_WAVE == 6) WAIT_VM(6); else if (B_PER_WAVE == 5) WAIT_VM(5); else if (B_PER_WAVE == 4) WAIT_VM(4);
@@ -379,19 +391,21 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
 #undef WAIT_VM
 #undef BARRIER
 #undef READ_FRAGS
+#undef CHUNK_OFF
 
-template <int WAVES_M, int WAVES_N, int MB, int NB, int EPI>
+template <int WAVES_M, int WAVES_N, int MB, int NB, int EPI, int CK = CB_CK>
 static int launch_conv_cfg(const ConvBP &p, int n_tiles_total, hipStream_t st)
 {
     constexpr int BN = WAVES_N * NB * 32;
     constexpr int NT = WAVES_M * WAVES_N * 64;
-    const size_t smem = 65536 + 3 * (size_t)BN * 192 + (EPI_IS_FWD(EPI) ? orn_align((size_t)p.Nout * 4) : 0);   // + bias copy
-    auto kern = k_conv_nhwc_bf16<WAVES_M, WAVES_N, MB, NB, EPI>;
+    constexpr size_t LDS_IMG = (size_t)(CB_PH * CB_PW * CK * 2 + 1023) / 1024 * 1024 + (CK == CB_CK ? 3 : 9) * (size_t)BN * CK * 2;
+    const size_t smem = LDS_IMG + (EPI_IS_FWD(EPI) ? orn_align((size_t)p.Nout * 4) : 0);   // + bias copy
+    auto kern = k_conv_nhwc_bf16<WAVES_M, WAVES_N, MB, NB, EPI, CK>;
     static bool attr_done = false;
     if (!attr_done) {
         // opt in once for the largest request (bias copy up to 2048 channels)
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(65536 + 3 * (size_t)BN * 192 + 8192));
+                                           (int)(LDS_IMG + 8192));
         if (e != hipSuccess) { orn_set_error("conv_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
@@ -420,8 +434,9 @@ static unsigned conv_magic(int d)
 }
 
 // fwd: N tile 128 (waves 4x2, wave tile 64 px x 64 ch); dgrad: N = 96 in one tile (waves 8x1, 32 px x 96 ch)
+// c_real: input channels that are not zero padding (<= Cin); <= 32 of them take the narrow form (forward of a non-last block)
 int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p, int H, int W, int Cin, int O, int s,
-                             h16 *z, h16 *apad, hipStream_t st)
+                             h16 *z, h16 *apad, hipStream_t st, int c_real)
 {
     ORN_REQUIRE(Cin % CB_CK == 0 && O % 128 == 0 && O % (s * s) == 0, "conv_bf16_fwd: unsupported Cin=%d O=%d s=%d", Cin, O, s);
     ConvBP p = {};
@@ -438,6 +453,7 @@ int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p
     const float cost_whole = (float)orn_cdiv(ptiles, 256) * nt_total;
     const float cost_split = (float)orn_cdiv(ptiles * nt_total, 256) * 1.3f;
     p.n_tiles_per_wg = (ptiles >= 512 || cost_whole <= cost_split) ? nt_total : 1;
+    if (apad && c_real > 0 && c_real <= 32) return launch_conv_cfg<4, 2, 2, 2, EPI_B_FWD, 32>(p, nt_total, st);
     return apad ? launch_conv_cfg<4, 2, 2, 2, EPI_B_FWD>(p, nt_total, st) : launch_conv_cfg<4, 2, 2, 2, EPI_B_FWD_LAST>(p, nt_total, st);
 }
 
@@ -1259,8 +1275,8 @@ int orn_launch_head_bwd_bf16(const h16 *z, const float *w, const float *out, con
 
 // ---- type-erased operation table for the engine (one per compiled element type) -----------------------
 static int a_conv_fwd(const void *xpad, const void *wb, const float *bias_p, int H, int W, int Cin, int O, int s, void *z, void *apad,
-                      hipStream_t st)
-{ return orn_launch_conv_bf16_fwd((const h16 *)xpad, (const h16 *)wb, bias_p, H, W, Cin, O, s, (h16 *)z, (h16 *)apad, st); }
+                      hipStream_t st, int c_real)
+{ return orn_launch_conv_bf16_fwd((const h16 *)xpad, (const h16 *)wb, bias_p, H, W, Cin, O, s, (h16 *)z, (h16 *)apad, st, c_real); }
 static int a_conv_dgrad(const void *dypad, const void *wd, int H, int W, int O, int C, const void *zprev, void *dyprev, int sp,
                         float *dx_f32, hipStream_t st)
 { return orn_launch_conv_bf16_dgrad((const h16 *)dypad, (const h16 *)wd, H, W, O, C, (const h16 *)zprev, (h16 *)dyprev, sp, dx_f32, st); }
@@ -1367,7 +1383,7 @@ extern "C" int orn_conv3x3_ps_silu_fwd_bf16(const float *x, const float *wf, con
     const int Cn = O / (s * s), Hs = H * s, Ws = W * s;
     ORN_TRY(orn_launch_nchw_to_nhwc_pad_bf16(x, C, C, H, W, b.xpad, st));
     ORN_TRY(orn_launch_prep_weights_bf16(wf, bf, O, C, s, b.wb, b.wd, b.biasp, st));
-    ORN_TRY(orn_launch_conv_bf16_fwd(b.xpad, b.wb, b.biasp, H, W, C, O, s, b.zb, b.apad, st));
+    ORN_TRY(orn_launch_conv_bf16_fwd(b.xpad, b.wb, b.biasp, H, W, C, O, s, b.zb, b.apad, st, C));
     const long n = (long)Cn * Hs * Ws;
     if (z) hipLaunchKernelGGL(k_nhwc_bf16_to_nchw_f32, dim3(orn_cdiv(n, 256)), dim3(256), 0, st, b.zb, Cn, Hs, Ws, 0, z);
     hipLaunchKernelGGL(k_nhwc_bf16_to_nchw_f32, dim3(orn_cdiv(n, 256)), dim3(256), 0, st, b.apad, Cn, Hs, Ws, 1, a);
@@ -1404,7 +1420,7 @@ extern "C" int orn_conv_nhwc_bf16_fwd(const void *xpad, const void *wb, const fl
 {
     ORN_REQUIRE(xpad && wb && z, "conv_nhwc_bf16_fwd: null pointer");
     return orn_launch_conv_bf16_fwd((const h16 *)xpad, (const h16 *)wb, bias_p, H, W, C, O, s, (h16 *)z, (h16 *)apad,
-                                    (hipStream_t)stream);
+                                    (hipStream_t)stream, C);
 }
 
 extern "C" int orn_wgrad_nhwc_bf16(const void *xpad, const void *dypad, int H, int W, int C, int O, int s, float *slabs,

@@ -354,7 +354,7 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
         } else {
             if (i == ff && !e->stage0) ORN_TRY(e->ops->to_nhwc(x, l.C, ORN_FAST_C, l.H, l.W, b.xpad, st));
             if (e->prof) (void)hipEventRecord(e->prof_ev[2 * i], st);
-            ORN_TRY(e->ops->conv_fwd(b.xpad, b.wb, b.biasp, l.H, l.W, ORN_FAST_C, l.O, l.s, b.zb, (i + 1 < nl) ? e->L[i + 1].xpad : nullptr, st));
+            ORN_TRY(e->ops->conv_fwd(b.xpad, b.wb, b.biasp, l.H, l.W, ORN_FAST_C, l.O, l.s, b.zb, (i + 1 < nl) ? e->L[i + 1].xpad : nullptr, st, l.C));
             if (e->prof) (void)hipEventRecord(e->prof_ev[2 * i + 1], st);
         }
     }
@@ -553,5 +553,5 @@ extern "C" int orn_conv_nhwc_f16_fwd(const void *xpad, const void *wb, const flo
                                      int s, void *z, void *apad, void *stream)
 {
     ORN_REQUIRE(xpad && wb && z, "conv_nhwc_f16_fwd: null pointer");
-    return orn_half_ops_f16()->conv_fwd(xpad, wb, bias_p, H, W, C, O, s, z, apad, (hipStream_t)stream);
+    return orn_half_ops_f16()->conv_fwd(xpad, wb, bias_p, H, W, C, O, s, z, apad, (hipStream_t)stream, C);
 }

@@ -89,7 +89,7 @@ struct OrnWgradReduce { const float *slabs; int H, W, C, O, s; float gscale; flo
 struct OrnWgradJob { const void *xpad, *dypad; int H, W, C, O, s; float *slabs; };   // wgrad into slabs, reduction deferred
 struct OrnHalfOps {
     int (*conv_fwd)(const void *xpad, const void *wb, const float *bias_p, int H, int W, int Cin, int O, int s, void *z, void *apad,
-                    hipStream_t st);
+                    hipStream_t st, int c_real);   // c_real <= Cin: input channels that are not zero padding
     int (*conv_dgrad)(const void *dypad, const void *wd, int H, int W, int O, int C, const void *zprev, void *dyprev, int sp,
                       float *dx_f32, hipStream_t st);
     size_t (*wgrad_ws_floats)(int H, int W, int O);
