@@ -63,6 +63,29 @@ __device__ __forceinline__ float orn_wave_sum(float v)
     return v;
 }
 
+// One output neuron of y = silu(W x + b) per wave (B rows of x); shared by k_linear_silu and the merge launches that carry
+// the stem's linear layers as extra work-groups (orn_merge.hip).
+struct OrnLinearJob {
+    const float *x; const int *row_idx; size_t row_stride; const float *w, *bias; int B, K, N; float *pre, *y;
+};
+__device__ __forceinline__ void orn_linear_silu_wave(const OrnLinearJob &j, int wave, int lane)
+{
+    if (wave >= j.N) return;
+    const float *x = j.x;
+    if (j.row_idx) x += (size_t)(*j.row_idx) * j.row_stride;
+    const float *wr = j.w + (size_t)wave * j.K;
+    for (int b = 0; b < j.B; ++b) {
+        float acc = 0.f;
+        for (int k = lane; k < j.K; k += 64) acc = fmaf(wr[k], x[(size_t)b * j.K + k], acc);
+        acc = orn_wave_sum(acc);
+        if (lane == 0) {
+            const float p = acc + j.bias[wave];
+            j.pre[(size_t)b * j.N + wave] = p;
+            j.y[(size_t)b * j.N + wave] = p / (1.0f + expf(-p));
+        }
+    }
+}
+
 // Block-wide sum for blockDim.x <= 1024 (multiple of 64); result valid in thread 0. Deterministic.
 __device__ __forceinline__ float orn_block_sum(float v, float *smem /* >= 16 floats */)
 {

@@ -110,20 +110,8 @@ __global__ void k_linear_silu(const float *__restrict__ x, const int *__restrict
                               const float *__restrict__ w, const float *__restrict__ bias, int B, int K, int N,
                               float *__restrict__ pre, float *__restrict__ y)
 {
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (wave >= N) return;
-    if (row_idx) x += (size_t)(*row_idx) * row_stride;
-    const float *wr = w + (size_t)wave * K;
-    for (int b = 0; b < B; ++b) {
-        float acc = 0.f;
-        for (int k = lane; k < K; k += 64) acc = fmaf(wr[k], x[(size_t)b * K + k], acc);
-        acc = orn_wave_sum(acc);
-        if (lane == 0) {
-            const float p = acc + bias[wave];
-            pre[(size_t)b * N + wave] = p;
-            y[(size_t)b * N + wave] = p / (1.0f + expf(-p));
-        }
-    }
+    const OrnLinearJob j = {x, row_idx, row_stride, w, bias, B, K, N, pre, y};
+    orn_linear_silu_wave(j, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, threadIdx.x & 63);
 }
 
 int orn_launch_linear_silu(const float *x, const int *row_idx, size_t row_stride, const float *w, const float *b,

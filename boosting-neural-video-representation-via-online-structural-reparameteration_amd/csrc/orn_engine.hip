@@ -320,16 +320,19 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
     const orn_engine_desc &d = e->d;
     const int Nout = d.fc_h * d.fc_w * d.fc_dim;
     float *P = e->params;
-    ORN_TRY(orn_launch_linear_silu(embeds, row_idx, d.embed_len, P + d.stem_w0, P + d.stem_b0, 1, d.embed_len, d.stem_dim,
-                                   e->pre1, e->h1, st));
-    ORN_TRY(orn_launch_linear_silu(e->h1, nullptr, 0, P + d.stem_w1, P + d.stem_b1, 1, d.stem_dim, Nout, e->pre2, e->h2, st));
+    const OrnLinearJob lin1 = {embeds, row_idx, (size_t)d.embed_len, P + d.stem_w0, P + d.stem_b0, 1, d.embed_len, d.stem_dim, e->pre1, e->h1};
+    const OrnLinearJob lin2 = {e->h1, nullptr, 0, P + d.stem_w1, P + d.stem_b1, 1, d.stem_dim, Nout, e->pre2, e->h2};
     const float *x = e->h2;
     const int nl = d.n_layers, ff = e->ff;
     if (d.erb) {
-        // online re-parameterisation of every layer (model.py:534): weights only, so all layers up front
-        ORN_TRY(orn_launch_merge_group(e->merge_tables, 0, e->merge_tiles[0], st));
-        ORN_TRY(orn_launch_merge_group(e->merge_tables, 1, e->merge_tiles[1], st));
-        // (the bias merge b3x3 + (b1x3 + b3x1) rides in the S launch's first tile column)
+        // online re-parameterisation of every layer (model.py:534): weights only, so all layers up front -- two grouped
+        // launches (T, then S with the bias merge b3x3 + (b1x3 + b3x1) in its first tile column), each carrying one of
+        // the stem's two linear layers as extra work-groups
+        ORN_TRY(orn_launch_merge_group_linear(e->merge_tables, 0, e->merge_tiles[0], lin1, st));
+        ORN_TRY(orn_launch_merge_group_linear(e->merge_tables, 1, e->merge_tiles[1], lin2, st));
+    } else {
+        ORN_TRY(orn_launch_linear_silu(lin1.x, lin1.row_idx, lin1.row_stride, lin1.w, lin1.bias, 1, lin1.K, lin1.N, lin1.pre, lin1.y, st));
+        ORN_TRY(orn_launch_linear_silu(lin2.x, nullptr, 0, lin2.w, lin2.bias, 1, lin2.K, lin2.N, lin2.pre, lin2.y, st));
     }
     if (ff < nl) {      // bf16 operand copies of every fast layer's merged kernel, one launch
         OrnPrepLayer pl[ORN_MAX_LAYERS];

@@ -47,6 +47,7 @@ size_t orn_merge_group_bytes();
 int orn_merge_groups_build(void *dev_tables, int n_layers, const OrnMergeLayer *L, int bwd_h16);
 int orn_merge_group_tiles(int which, int n_layers, const OrnMergeLayer *L);
 int orn_launch_merge_group(const void *dev_tables, int which, int tiles, hipStream_t st);
+int orn_launch_merge_group_linear(const void *dev_tables, int which, int tiles, const OrnLinearJob &job, hipStream_t st);
 int orn_launch_merge_bias(const float *b3x3, const float *b1x3, const float *b3x1, int O, float *bf, hipStream_t st);
 int orn_launch_merge_bwd_tail(const float *g, const float *dbf, int C, int O, float *d3x3, float *db3x3, float *d3x1,
                               float *db3x1, float *d1x3, float *db1x3, const float *dw1p, float *dw1, hipStream_t st);

@@ -216,6 +216,25 @@ __global__ void __launch_bounds__(256) k_gemm_f32_grouped(const GemmGroup *__res
     else gemm_body(p, rem % tn, rem / tn, bz);
 }
 
+// The same launch with one of the stem's linear layers riding along as trailing work-groups (4 output neurons each): the
+// stem and the merge are independent latency-bound chains at the head of the step, and a graph node costs ~5 us by itself.
+__global__ void __launch_bounds__(256) k_gemm_f32_grouped_linear(const GemmGroup *__restrict__ g, OrnLinearJob job, int gemm_tiles)
+{
+    // the GEMM tiles are the long latency chains: they are dispatched first, the short linear work-groups behind them
+    if ((int)blockIdx.x >= gemm_tiles) {
+        orn_linear_silu_wave(job, (blockIdx.x - gemm_tiles) * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+        return;
+    }
+    const int bid = blockIdx.x;
+    int pi = 0;
+    while (pi + 1 < g->n && bid >= g->tile_start[pi + 1]) ++pi;
+    const GemmP p = g->prob[pi];
+    const int local = bid - g->tile_start[pi];
+    const int tn = (p.N + GT - 1) / GT, tm = (p.M + GT - 1) / GT;
+    const int bz = local / (tn * tm), rem = local - bz * tn * tm;
+    gemm_body(p, rem % tn, rem / tn, bz);
+}
+
 static void finish_gemm(GemmP &p)
 {
     p.a_kfast = (labs(p.sak) <= labs(p.sam)) ? 1 : 0;
@@ -452,6 +471,16 @@ int orn_launch_merge_group(const void *dev_tables, int which, int tiles, hipStre
     const GemmGroup *g = (const GemmGroup *)dev_tables + which;
     hipLaunchKernelGGL(k_gemm_f32_grouped, dim3(tiles), dim3(256), 0, st, g);
     ORN_LAUNCH_CHECK("merge_group");
+    return 0;
+}
+
+// fp32 groups only (which = 0 / 1: the forward merge)
+int orn_launch_merge_group_linear(const void *dev_tables, int which, int tiles, const OrnLinearJob &job, hipStream_t st)
+{
+    const GemmGroup *g = (const GemmGroup *)dev_tables + which;
+    const int lin_blocks = orn_cdiv(job.N, 4);
+    hipLaunchKernelGGL(k_gemm_f32_grouped_linear, dim3(tiles + lin_blocks), dim3(256), 0, st, g, job, tiles);
+    ORN_LAUNCH_CHECK("merge_group_linear");
     return 0;
 }
 
