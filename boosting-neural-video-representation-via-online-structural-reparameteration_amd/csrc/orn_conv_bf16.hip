@@ -689,9 +689,37 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p) { wgrad_b
 // Several layers in one launch (problems in the order given, each on a multiple-of-8 block range so the XCD decode holds):
 // the small layers' wgrads do not fill the chip one at a time (72 / 216 / 360 work-groups for 512 slots at 720p), and
 // nothing but the deferred reduction consumes them.
-struct WgradBPAll { int n; int start[ORN_MAX_LAYERS + 1]; WgradBP p[ORN_MAX_LAYERS]; };
+// dw/db = gscale * sum over blocks of the head backward's per-block partials [blocks][3C+3]: one work-group per column, lane
+// t sums rows t, t+256, .. in ascending order, fixed-order block tree after (deterministic).
+__device__ __forceinline__ void head_finish_body(const float *__restrict__ partial, int blocks, int C, float gscale, float *__restrict__ dw,
+                                                 float *__restrict__ db, int col, float *sred /* 256 floats of LDS */)
+{
+    const int n = 3 * C + 3, t = threadIdx.x;
+    float acc = 0.f;
+    for (int r = t; r < blocks; r += 256) acc += partial[(size_t)r * n + col];
+    sred[t] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) sred[t] += sred[t + w];
+        __syncthreads();
+    }
+    if (t == 0) {
+        const float v = sred[0] * gscale;
+        if (col < 3 * C) dw[col] = v;
+        else db[col - 3 * C] = v;
+    }
+}
+
+// The head's dW/db reduction (needed by Adam only) rides along as trailing work-groups: one graph node less.
+struct WgradBPAll { int n; int start[ORN_MAX_LAYERS + 1]; WgradBP p[ORN_MAX_LAYERS]; OrnHeadFinish hf; };
 __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16_all(WgradBPAll a)
 {
+    if ((int)blockIdx.x >= a.start[a.n]) {
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem_hf[];
+        head_finish_body(a.hf.partial, a.hf.blocks, a.hf.C, a.hf.gscale, a.hf.dw, a.hf.db, (int)blockIdx.x - a.start[a.n],
+                         reinterpret_cast<float *>(smem_hf));
+        return;
+    }
     int k = 0;
     while (k + 1 < a.n && (int)blockIdx.x >= a.start[k + 1]) ++k;
     k = __builtin_amdgcn_readfirstlane(k);
@@ -790,7 +818,7 @@ static int wgrad_fill(WgradBP &p, const h16 *xpad, const h16 *dypad, int H, int 
 }
 
 // slabs only (no reduction), several layers in one launch
-int orn_launch_wgrad_bf16_batch(int n, const OrnWgradJob *J, hipStream_t st)
+int orn_launch_wgrad_bf16_batch(int n, const OrnWgradJob *J, hipStream_t st, const OrnHeadFinish *hf)
 {
     if (n == 0) return 0;
     ORN_REQUIRE(n <= ORN_MAX_LAYERS, "wgrad_batch: %d layers", n);
@@ -803,6 +831,8 @@ int orn_launch_wgrad_bf16_batch(int n, const OrnWgradJob *J, hipStream_t st)
         total += 3 * a.p[i].n_otiles * a.p[i].S;        // S % 8 == 0: every start is a multiple of 8
     }
     a.start[n] = total;
+    a.hf = OrnHeadFinish{};
+    if (hf) { a.hf = *hf; total += 3 * hf->C + 3; }
     hipLaunchKernelGGL(k_wgrad_nhwc_bf16_all, dim3(total), dim3(256), 2 * WB_BUF_BYTES, st, a);
     ORN_LAUNCH_CHECK("wgrad_nhwc_bf16_all");
     return 0;
@@ -1214,26 +1244,11 @@ k_head_bwd_nhwc_bf16(const h16 *__restrict__ z, const float *__restrict__ w, con
     }
 }
 
-// dw/db = gscale * sum over blocks of the per-block partials [blocks][3C+3]: one work-group per column, lane t sums
-// rows t, t+256, .. in ascending order, fixed-order block tree after (deterministic).
 __global__ void __launch_bounds__(256) k_head_bf16_finish(const float *__restrict__ partial, int blocks, int C, float gscale,
                                                           float *__restrict__ dw, float *__restrict__ db)
 {
     __shared__ float sred[256];
-    const int n = 3 * C + 3, col = blockIdx.x, t = threadIdx.x;
-    float acc = 0.f;
-    for (int r = t; r < blocks; r += 256) acc += partial[(size_t)r * n + col];
-    sred[t] = acc;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if (t < w) sred[t] += sred[t + w];
-        __syncthreads();
-    }
-    if (t == 0) {
-        const float v = sred[0] * gscale;
-        if (col < 3 * C) dw[col] = v;
-        else db[col - 3 * C] = v;
-    }
+    head_finish_body(partial, blocks, C, gscale, dw, db, blockIdx.x, sred);
 }
 
 #define HB_BLOCKS 512
@@ -1249,6 +1264,7 @@ int orn_launch_head_fwd_bf16(const h16 *z, const float *w, const float *b, int C
 }
 
 size_t orn_head_bwd_bf16_ws_floats(int C) { return (size_t)(HB_BLOCKS + 1) * (3 * C + 3); }
+int orn_head_bwd_bf16_blocks(int H, int W) { const int b = orn_cdiv((long)H * W, 64); return b > HB_BLOCKS ? HB_BLOCKS : b; }
 
 // gs_up: gradient scale carried by dypad (1 for bf16, 2^20 for fp16); dw/db are un-scaled here
 int orn_launch_head_bwd_bf16(const h16 *z, const float *w, const float *out, const float *dout, int C, int H, int W, int sigmoid,
@@ -1266,6 +1282,7 @@ int orn_launch_head_bwd_bf16(const h16 *z, const float *w, const float *out, con
     default: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<4>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, gs_up, dypad, partial); break;
     }
     ORN_LAUNCH_CHECK("head_bwd_bf16");
+    if (!dw) return 0;                  // deferred: rides along orn_launch_wgrad_bf16_batch (OrnHeadFinish)
     const size_t n = 3 * (size_t)C + 3;
     (void)red;
     hipLaunchKernelGGL(k_head_bf16_finish, dim3((unsigned)n), dim3(256), 0, st, partial, blocks, C, 1.0f / gs_up, dw, db);
@@ -1292,7 +1309,7 @@ static int a_head_bwd(const void *z, const float *w, const float *out, const flo
 { return orn_launch_head_bwd_bf16((const h16 *)z, w, out, dout, C, H, W, sigmoid, sp, gs_up, (h16 *)dypad, dw, db, ws, st); }
 
 const OrnHalfOps ops = {a_conv_fwd, a_conv_dgrad, orn_wgrad_bf16_ws_floats, a_wgrad, orn_launch_wgrad_bf16_batch, orn_launch_wgrad_reduce_all, orn_launch_prep_weights_bf16_all, a_to_nhwc,
-                        orn_launch_nhwc_to_nchw_f32, orn_dgrad_f32_slabs, a_head_fwd, orn_head_bwd_bf16_ws_floats, a_head_bwd};
+                        orn_launch_nhwc_to_nchw_f32, orn_dgrad_f32_slabs, a_head_fwd, orn_head_bwd_bf16_ws_floats, orn_head_bwd_bf16_blocks, a_head_bwd};
 
 #ifndef ORN_FP16
 // ================================================================================================

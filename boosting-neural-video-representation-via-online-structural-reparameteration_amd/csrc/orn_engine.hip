@@ -33,6 +33,7 @@ struct orn_engine {
     float *img, *dimg, *stats;
     float *loss_ws;
     float *scratch;                  // shared scratch for the backward kernels
+    float *head_ws;                  // 16-bit head backward: per-block partials (live until the deferred finish)
     OrnStepCur *cur;                 // state of the step in flight (device)
     LayerBuf L[ORN_MAX_LAYERS];
     int Hout, Wout, Cn_last;
@@ -170,12 +171,13 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
     const size_t s3 = (ff < d->n_layers) ? orn_half_ops_bf16()->head_bwd_ws_floats(Cn) : orn_head_bwd_ws_bytes(1, Cn, H, W) / 4;
     if (s3 > scratch) scratch = s3;
     float *scr = take(scratch);
+    float *head_ws = (ff < d->n_layers) ? take(orn_half_ops_bf16()->head_bwd_ws_floats(Cn)) : nullptr;
     float *cur = take(16);
     float *mtab = d->erb ? take(orn_merge_group_bytes() / 4) : nullptr;
     float *mhtab = (d->erb && d->precision != 0) ? take(orn_merge_h16_table_bytes() / 4) : nullptr;
     if (e) {
         e->pre1 = pre1; e->h1 = h1; e->pre2 = pre2; e->h2 = h2; e->dh2 = dh2;
-        e->img = img; e->dimg = dimg; e->stats = stats; e->loss_ws = loss_ws; e->scratch = scr;
+        e->img = img; e->dimg = dimg; e->stats = stats; e->loss_ws = loss_ws; e->scratch = scr; e->head_ws = head_ws;
         e->cur = (OrnStepCur *)cur;
         for (int i = 0; i < d->n_layers; ++i) e->L[i] = L[i];
         e->Hout = H; e->Wout = W; e->Cn_last = Cn;
@@ -394,7 +396,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
     const int nl = d.n_layers, ff = e->ff;
     if (ff < nl)
         ORN_TRY(e->ops->head_bwd(e->L[nl - 1].zb, P + d.head_w, e->img, e->dimg, e->Cn_last, e->Hout, e->Wout, d.sigmoid,
-                                 d.layer[nl - 1].s, e->gs, e->L[nl - 1].dypad, G + d.head_w, G + d.head_b, e->scratch, st));
+                                 d.layer[nl - 1].s, e->gs, e->L[nl - 1].dypad, nullptr, nullptr, e->head_ws, st));   // dW / db: finished with the wgrad batch
     else
         ORN_TRY(orn_launch_head_bwd(e->L[nl - 1].a, P + d.head_w, e->img, e->dimg, 1, e->Cn_last, HWo, d.sigmoid, e->L[nl - 1].da,
                                     G + d.head_w, G + d.head_b, e->scratch, st));
@@ -434,7 +436,8 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
             const orn_layer_desc &l = d.layer[i];
             wj[nj++] = OrnWgradJob{e->L[i].xpad, e->L[i].dypad, l.H, l.W, l.C, l.O, l.s, e->L[i].wslab};
         }
-        ORN_TRY(e->ops->wgrad_batch(nj, wj, st));
+        const OrnHeadFinish hf = {e->head_ws, e->ops->head_bwd_blocks(e->Hout, e->Wout), e->Cn_last, 1.0f / e->gs, G + d.head_w, G + d.head_b};
+        ORN_TRY(e->ops->wgrad_batch(nj, wj, st, &hf));
         OrnWgradReduce wr[ORN_MAX_LAYERS];
         for (int i = ff; i < nl; ++i) {
             const orn_layer_desc &l = d.layer[i];

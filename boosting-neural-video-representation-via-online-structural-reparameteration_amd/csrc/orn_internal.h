@@ -87,6 +87,8 @@ int orn_launch_loss(const float *pred, const float *target, const int *frame_idx
 struct OrnPrepLayer { const float *wf, *bf; int O, C, s; void *wb, *wd; float *biasp; int Cp; };   // Cp: channel stride (0: = C)
 // deferred split-K reduction of a layer's wgrad slabs (wgrad called with dwf == nullptr leaves them in `slabs`)
 struct OrnWgradReduce { const float *slabs; int H, W, C, O, s; float gscale; float *dwf, *dbf; };
+// deferred reduction of the 16-bit head backward's per-block partials (head_bwd called with dw == nullptr leaves them in ws)
+struct OrnHeadFinish { const float *partial; int blocks, C; float gscale; float *dw, *db; };
 struct OrnWgradJob { const void *xpad, *dypad; int H, W, C, O, s; float *slabs; };   // wgrad into slabs, reduction deferred
 struct OrnHalfOps {
     int (*conv_fwd)(const void *xpad, const void *wb, const float *bias_p, int H, int W, int Cin, int O, int s, void *z, void *apad,
@@ -96,7 +98,7 @@ struct OrnHalfOps {
     size_t (*wgrad_ws_floats)(int H, int W, int O);
     int (*wgrad)(const void *xpad, const void *dypad, int H, int W, int C, int O, int s, float gscale, float *slabs, float *dwf,
                  float *dbf, hipStream_t st);
-    int (*wgrad_batch)(int n, const OrnWgradJob *J, hipStream_t st);           // several layers' slabs in one launch
+    int (*wgrad_batch)(int n, const OrnWgradJob *J, hipStream_t st, const OrnHeadFinish *hf);   // several layers' slabs in one launch (+ optional head finish)
     int (*wgrad_reduce_all)(int n, const OrnWgradReduce *L, hipStream_t st);   // all layers' reductions in one launch
     int (*prep_all)(int n, const OrnPrepLayer *L, hipStream_t st);
     int (*to_nhwc)(const float *src, int C, int Cp, int H, int W, void *dst, hipStream_t st);
@@ -104,6 +106,7 @@ struct OrnHalfOps {
     int (*dgrad_f32_slabs)(int H, int W, int O);
     int (*head_fwd)(const void *z, const float *w, const float *b, int C, size_t HW, int sigmoid, float *out, hipStream_t st);
     size_t (*head_bwd_ws_floats)(int C);
+    int (*head_bwd_blocks)(int H, int W);
     int (*head_bwd)(const void *z, const float *w, const float *out, const float *dout, int C, int H, int W, int sigmoid, int sp,
                     float gs_up, void *dypad, float *dw, float *db, float *ws, hipStream_t st);
 };
