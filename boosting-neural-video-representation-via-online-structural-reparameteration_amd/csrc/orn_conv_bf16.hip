@@ -111,13 +111,16 @@ struct ConvBP {
 // (the zero-padded narrow layer, forward only): its whole K = 9 x 32 fits LDS -- patch 22 KB + all nine [BN][32] weight
 // tiles 72 KB -- so an N tile is ONE rendezvous and 72 back-to-back MFMAs per wave instead of nine rounds of barrier +
 // counted wait + 24 MFMAs of which two thirds multiply zeros.  Rows are 64 B: 4 chunks, XOR swizzle (chunk ^ ((row >> 2) & 3)).
-template <int WAVES_M, int WAVES_N, int MB, int NB, int EPI, int CK = CB_CK>
+// ALLTAPS: all nine weight tiles of the (single) K chunk resident, one rendezvous per N tile -- the narrow form, and the
+// chunk-split dgrad of a layer with <= 32 real OUTPUT channels (N tile 32: 9 x 6 KB next to the 64 KB patch).
+template <int WAVES_M, int WAVES_N, int MB, int NB, int EPI, int CK = CB_CK, bool ALLTAPS = (CK != CB_CK)>
 __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP p)
 {
     constexpr bool NARROW = (CK != CB_CK);
     static_assert(CK == CB_CK || (CK == 32 && EPI_IS_FWD(EPI)), "narrow form: 32 channels, forward only");
     constexpr int NCH = CK / 8;                        // 16-byte chunks per LDS row
-    constexpr int NBUF = NARROW ? 9 : 3;               // weight tiles resident at once
+    static_assert(!NARROW || ALLTAPS, "the narrow form keeps all taps resident");
+    constexpr int NBUF = ALLTAPS ? 9 : 3;              // weight tiles resident at once
     constexpr int NT = WAVES_M * WAVES_N * 64;
     constexpr int BN = WAVES_N * NB * 32;
     static_assert(WAVES_M * MB == CB_TH, "M tile must be 8 rows of 32 pixels");
@@ -154,7 +157,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
     const int h0 = th * CB_TH, w0 = tw * CB_TW;
     const int H = p.H, W = p.W, Cin = p.Cin;
     const int q_base = (EPI == EPI_B_DGRAD_F32 && p.qsplit) ? (int)blockIdx.y : 0;   // chunk split: this WG's chunk
-    const int Q = (NARROW || (EPI == EPI_B_DGRAD_F32 && p.qsplit)) ? 1 : Cin / CB_CK;
+    const int Q = (ALLTAPS || (EPI == EPI_B_DGRAD_F32 && p.qsplit)) ? 1 : Cin / CB_CK;   // ALLTAPS dgrad: launched chunk-split
     if (EPI == EPI_B_DGRAD_F32 && p.qsplit) nt0 = 0;
     const int n_tiles = Q * 9;                         // weight tiles per N tile
 
@@ -250,13 +253,13 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
         if ((nti == 0 || Q > 1) && !(PDBG(p) & 2)) DMA_PATCH(0)
         DMA_B(0, nt, 0, 0)
         if (n_tiles > 1) DMA_B(1, nt, 0, 1)
-        if (NARROW) {                                  // the whole K of this N tile: taps 2..8 too, then the only rendezvous
+        if (ALLTAPS) {                                 // the whole K of this N tile: taps 2..8 too, then the only rendezvous
 #pragma unroll
             for (int tp = 2; tp < 9; ++tp) DMA_B(tp, nt, 0, tp)
         }
         WAIT_VM(0);
         BARRIER();
-        if (!NARROW && n_tiles > 2) DMA_B(2, nt, 0, 2)
+        if (!ALLTAPS && n_tiles > 2) DMA_B(2, nt, 0, 2)
         if (EPI_IS_FWD(EPI) && pending) FLUSH_DEFERRED()
         h16x8 fa[2][MB], fb[2][NB];
         // Chunks of 96 input channels outside, the nine taps inside and fully unrolled: tap, kernel row / column and the
@@ -266,7 +269,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
             for (int tap = 0; tap < 9; ++tap) {
                 const int tt = q * 9 + tap;
                 constexpr int dummy_ = 0; (void)dummy_;
-                const int buf = NARROW ? tap : tap % 3;
+                const int buf = ALLTAPS ? tap : tap % 3;
                 const int ti = tap / 3, tj = tap - ti * 3;
                 const bool last_chunk = (q + 1 >= Q);
                 const bool has_next = (tap < 8) || !last_chunk;
@@ -287,7 +290,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
 #pragma unroll
                         for (int j = 0; j < NB; ++j) acc[i][j] = MFMA_H16(fb[ks & 1][j], fa[ks & 1][i], acc[i][j]);
                 }
-                if (!NARROW && has_next) {
+                if (!ALLTAPS && has_next) {
                     // tile tt+1 was issued two tiles ago: let only tile tt+2's DMA stay in flight, then rendezvous
                     if (tap < 7 || !last_chunk) {
                         if (B_PER_WAVE == 6) WAIT_VM(6); else if (B_PER_WAVE == 5) WAIT_VM(5); else if (B_PER_WAVE == 4) WAIT_VM(4);
@@ -393,14 +396,14 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
 #undef READ_FRAGS
 #undef CHUNK_OFF
 
-template <int WAVES_M, int WAVES_N, int MB, int NB, int EPI, int CK = CB_CK>
+template <int WAVES_M, int WAVES_N, int MB, int NB, int EPI, int CK = CB_CK, bool ALLTAPS = (CK != CB_CK)>
 static int launch_conv_cfg(const ConvBP &p, int n_tiles_total, hipStream_t st)
 {
     constexpr int BN = WAVES_N * NB * 32;
     constexpr int NT = WAVES_M * WAVES_N * 64;
-    constexpr size_t LDS_IMG = (size_t)(CB_PH * CB_PW * CK * 2 + 1023) / 1024 * 1024 + (CK == CB_CK ? 3 : 9) * (size_t)BN * CK * 2;
+    constexpr size_t LDS_IMG = (size_t)(CB_PH * CB_PW * CK * 2 + 1023) / 1024 * 1024 + (ALLTAPS ? 9 : 3) * (size_t)BN * CK * 2;
     const size_t smem = LDS_IMG + (EPI_IS_FWD(EPI) ? orn_align((size_t)p.Nout * 4) : 0);   // + bias copy
-    auto kern = k_conv_nhwc_bf16<WAVES_M, WAVES_N, MB, NB, EPI, CK>;
+    auto kern = k_conv_nhwc_bf16<WAVES_M, WAVES_N, MB, NB, EPI, CK, ALLTAPS>;
     static bool attr_done = false;
     if (!attr_done) {
         // opt in once for the largest request (bias copy up to 2048 channels)
@@ -491,8 +494,10 @@ __global__ void __launch_bounds__(256) k_dgrad_finish(const float *__restrict__ 
 
 // dx_f32 alone: fp32 output slabs (layer below is fp32).  zprev/dyprev alone: fused epilogue.  Both: dx_f32 is scratch for
 // orn_dgrad_f32_slabs(H, W, O) partial slabs and the result is finished into dyprev (small images).
+// c_real (fp32-output form only): output channels that are not zero padding; <= 32 of them on a chunk-split launch take the
+// all-taps-resident N = 32 form and only channels [0, 32) of the slabs are written
 int orn_launch_conv_bf16_dgrad(const h16 *dypad, const h16 *wd, int H, int W, int O, int C, const h16 *zprev,
-                               h16 *dyprev, int sp, float *dx_f32, hipStream_t st)
+                               h16 *dyprev, int sp, float *dx_f32, hipStream_t st, int c_real)
 {
     ORN_REQUIRE(O % CB_CK == 0 && C == 96, "conv_bf16_dgrad: unsupported O=%d C=%d", O, C);
     ConvBP p = {};
@@ -505,6 +510,7 @@ int orn_launch_conv_bf16_dgrad(const h16 *dypad, const h16 *wd, int H, int W, in
     p.mSp = conv_magic(sp);
     if (dx_f32) {
         p.qsplit = (p.tiles_w * p.tiles_h < 128 && O / CB_CK > 1) ? 1 : 0;   // few pixel tiles: one work-group per input chunk
+        if (!zprev && p.qsplit && c_real > 0 && c_real <= 32) return launch_conv_cfg<8, 1, 1, 1, EPI_B_DGRAD_F32, CB_CK, true>(p, 1, st);
         if (!zprev) return launch_conv_cfg<8, 1, 1, 3, EPI_B_DGRAD_F32>(p, 1, st);
         ORN_REQUIRE(dyprev && sp >= 1 && H % sp == 0 && W % sp == 0 && p.qsplit, "conv_bf16_dgrad: bad split-epilogue arguments");
         p.zprev = nullptr; p.dyprev = nullptr;
@@ -1295,8 +1301,8 @@ static int a_conv_fwd(const void *xpad, const void *wb, const float *bias_p, int
                       hipStream_t st, int c_real)
 { return orn_launch_conv_bf16_fwd((const h16 *)xpad, (const h16 *)wb, bias_p, H, W, Cin, O, s, (h16 *)z, (h16 *)apad, st, c_real); }
 static int a_conv_dgrad(const void *dypad, const void *wd, int H, int W, int O, int C, const void *zprev, void *dyprev, int sp,
-                        float *dx_f32, hipStream_t st)
-{ return orn_launch_conv_bf16_dgrad((const h16 *)dypad, (const h16 *)wd, H, W, O, C, (const h16 *)zprev, (h16 *)dyprev, sp, dx_f32, st); }
+                        float *dx_f32, hipStream_t st, int c_real)
+{ return orn_launch_conv_bf16_dgrad((const h16 *)dypad, (const h16 *)wd, H, W, O, C, (const h16 *)zprev, (h16 *)dyprev, sp, dx_f32, st, c_real); }
 static int a_wgrad(const void *xpad, const void *dypad, int H, int W, int C, int O, int s, float gscale, float *slabs, float *dwf,
                    float *dbf, hipStream_t st)
 { return orn_launch_wgrad_bf16((const h16 *)xpad, (const h16 *)dypad, H, W, C, O, s, gscale, slabs, dwf, dbf, st); }
@@ -1425,7 +1431,7 @@ extern "C" int orn_conv3x3_ps_silu_bwd_bf16(const float *x, const float *wf, con
     ORN_LAUNCH_CHECK("make_dy_bf16");
     ORN_TRY(orn_launch_wgrad_bf16(b.xpad, b.dypad, H, W, C, O, s, 1.0f, b.slabs, dwf, dbf, st));
     if (dx) {
-        ORN_TRY(orn_launch_conv_bf16_dgrad(b.dypad, b.wd, H, W, O, C, nullptr, nullptr, 1, b.dxn, st));
+        ORN_TRY(orn_launch_conv_bf16_dgrad(b.dypad, b.wd, H, W, O, C, nullptr, nullptr, 1, b.dxn, st, C));
         ORN_TRY(orn_launch_nhwc_to_nchw_f32(b.dxn, C, C, H, W, orn_dgrad_f32_slabs(H, W, O), 1.0f, dx, st));
     }
     return 0;
@@ -1450,7 +1456,7 @@ extern "C" int orn_dgrad_nhwc_bf16(const void *dypad, const void *wd, int H, int
                                    void *dyprev, int sp, void *stream)
 {
     return orn_launch_conv_bf16_dgrad((const h16 *)dypad, (const h16 *)wd, H, W, O, C, (const h16 *)zprev, (h16 *)dyprev, sp,
-                                      nullptr, (hipStream_t)stream);
+                                      nullptr, (hipStream_t)stream, C);
 }
 
 extern "C" void orn_debug_set(int flags) { set_debug(flags); }   // timing experiments only (tools/probes)

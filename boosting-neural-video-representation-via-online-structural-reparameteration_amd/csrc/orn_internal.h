@@ -94,7 +94,7 @@ struct OrnHalfOps {
     int (*conv_fwd)(const void *xpad, const void *wb, const float *bias_p, int H, int W, int Cin, int O, int s, void *z, void *apad,
                     hipStream_t st, int c_real);   // c_real <= Cin: input channels that are not zero padding
     int (*conv_dgrad)(const void *dypad, const void *wd, int H, int W, int O, int C, const void *zprev, void *dyprev, int sp,
-                      float *dx_f32, hipStream_t st);
+                      float *dx_f32, hipStream_t st, int c_real);   // c_real: output channels that are not zero padding
     size_t (*wgrad_ws_floats)(int H, int W, int O);
     int (*wgrad)(const void *xpad, const void *dypad, int H, int W, int C, int O, int s, float gscale, float *slabs, float *dwf,
                  float *dbf, hipStream_t st);
