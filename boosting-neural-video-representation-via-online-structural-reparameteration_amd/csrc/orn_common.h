@@ -63,6 +63,29 @@ __device__ __forceinline__ float orn_wave_sum(float v)
     return v;
 }
 
+// Last stem kernel (first linear layer's dW / db from `nslab` partial rows of dh1): one output row per 128 threads.  Shared by
+// k_linear_silu_bwd_w_slabs and the wgrad batch launch that carries it as trailing work-groups (Adam is its only consumer).
+struct OrnStemW0Job {
+    const float *x; const int *row_idx; size_t row_stride; const float *pre, *dy_slabs; int nslab, K, N; float *dpre, *dw, *db;
+};
+// t in [0, 128); sh: 2 floats of LDS private to the row's two waves; contains a work-group barrier (every thread must call)
+__device__ __forceinline__ void orn_stem_w0_row(const OrnStemW0Job &j, int o, int t, float *sh)
+{
+    const bool ok = o < j.N;
+    const float *x = j.x;
+    if (j.row_idx) x += (size_t)(*j.row_idx) * j.row_stride;
+    float v = 0.f;
+    if (ok)
+        for (int r = t; r < j.nslab; r += 128) v += j.dy_slabs[(size_t)r * j.N + o];
+    v = orn_wave_sum(v);
+    if ((t & 63) == 0) sh[t >> 6] = v;
+    __syncthreads();
+    if (!ok) return;
+    const float d = (sh[0] + sh[1]) * orn_silu_grad_exact(j.pre[o]);
+    if (t == 0) { j.dpre[o] = d; j.db[o] = d; }
+    for (int k = t; k < j.K; k += 128) j.dw[(size_t)o * j.K + k] = d * x[k];
+}
+
 // One output neuron of y = silu(W x + b) per wave (B rows of x); shared by k_linear_silu and the merge launches that carry
 // the stem's linear layers as extra work-groups (orn_merge.hip).
 struct OrnLinearJob {

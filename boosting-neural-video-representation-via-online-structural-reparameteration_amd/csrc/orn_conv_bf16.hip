@@ -717,9 +717,16 @@ __device__ __forceinline__ void head_finish_body(const float *__restrict__ parti
 }
 
 // The head's dW/db reduction (needed by Adam only) rides along as trailing work-groups: one graph node less.
-struct WgradBPAll { int n; int start[ORN_MAX_LAYERS + 1]; WgradBP p[ORN_MAX_LAYERS]; OrnHeadFinish hf; };
+struct WgradBPAll { int n; int start[ORN_MAX_LAYERS + 1]; WgradBP p[ORN_MAX_LAYERS]; OrnHeadFinish hf; int hf_blocks; OrnStemW0Job w0; };
 __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16_all(WgradBPAll a)
 {
+    if ((int)blockIdx.x >= a.start[a.n] + a.hf_blocks) {        // stem: two output rows per work-group
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem_w0[];
+        const int half = threadIdx.x >> 7;
+        orn_stem_w0_row(a.w0, ((int)blockIdx.x - a.start[a.n] - a.hf_blocks) * 2 + half, threadIdx.x & 127,
+                        reinterpret_cast<float *>(smem_w0) + 2 * half);
+        return;
+    }
     if ((int)blockIdx.x >= a.start[a.n]) {
         extern __shared__ __attribute__((aligned(16))) unsigned char smem_hf[];
         head_finish_body(a.hf.partial, a.hf.blocks, a.hf.C, a.hf.gscale, a.hf.dw, a.hf.db, (int)blockIdx.x - a.start[a.n],
@@ -824,7 +831,7 @@ static int wgrad_fill(WgradBP &p, const h16 *xpad, const h16 *dypad, int H, int 
 }
 
 // slabs only (no reduction), several layers in one launch
-int orn_launch_wgrad_bf16_batch(int n, const OrnWgradJob *J, hipStream_t st, const OrnHeadFinish *hf)
+int orn_launch_wgrad_bf16_batch(int n, const OrnWgradJob *J, hipStream_t st, const OrnHeadFinish *hf, const OrnStemW0Job *w0)
 {
     if (n == 0) return 0;
     ORN_REQUIRE(n <= ORN_MAX_LAYERS, "wgrad_batch: %d layers", n);
@@ -838,7 +845,10 @@ int orn_launch_wgrad_bf16_batch(int n, const OrnWgradJob *J, hipStream_t st, con
     }
     a.start[n] = total;
     a.hf = OrnHeadFinish{};
-    if (hf) { a.hf = *hf; total += 3 * hf->C + 3; }
+    a.hf_blocks = 0;
+    if (hf) { a.hf = *hf; a.hf_blocks = 3 * hf->C + 3; total += a.hf_blocks; }
+    a.w0 = OrnStemW0Job{};
+    if (w0) { a.w0 = *w0; total += orn_cdiv(w0->N, 2); }
     hipLaunchKernelGGL(k_wgrad_nhwc_bf16_all, dim3(total), dim3(256), 2 * WB_BUF_BYTES, st, a);
     ORN_LAUNCH_CHECK("wgrad_nhwc_bf16_all");
     return 0;

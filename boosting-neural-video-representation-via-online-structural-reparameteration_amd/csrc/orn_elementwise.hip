@@ -261,7 +261,7 @@ k_stem_bwd_l2(const float *__restrict__ w, const float *__restrict__ x, const fl
 
 int orn_launch_stem_bwd(const float *embed, const int *row_idx, size_t row_stride, const float *w1, const float *pre1,
                         const float *h1, const float *pre2, const float *dh2, int B, int E, int Hd, int Nout,
-                        float *dw0, float *db0, float *dw1, float *db1, float *ws, hipStream_t st, int dh2_nslab)
+                        float *dw0, float *db0, float *dw1, float *db1, float *ws, hipStream_t st, int dh2_nslab, OrnStemW0Job *defer_w0)
 {
     // ws: dpre2 [B*Nout] | dpre1 [B*Hd] | dh1 [B*Hd] | partial [CHUNKS*B*Hd]
     float *dpre2 = ws;
@@ -273,6 +273,10 @@ int orn_launch_stem_bwd(const float *embed, const int *row_idx, size_t row_strid
         hipLaunchKernelGGL(k_stem_bwd_l2, dim3(nwg), dim3(256), 0, st, w1, h1, pre2, dh2, dh2_nslab, (size_t)Nout, Hd, Nout, dw1, db1,
                            partial);
         ORN_LAUNCH_CHECK("stem_bwd_l2");
+        if (defer_w0) {      // the caller appends this job to a later launch (orn_stem_w0_row)
+            *defer_w0 = OrnStemW0Job{embed, row_idx, row_stride, pre1, partial, nwg, E, Hd, dpre1, dw0, db0};
+            return 0;
+        }
         hipLaunchKernelGGL(k_linear_silu_bwd_w_slabs, dim3(Hd), dim3(128), 0, st, embed, row_idx, row_stride, pre1, partial, nwg, E, Hd,
                            dpre1, dw0, db0);
         ORN_LAUNCH_CHECK("stem_bwd_w0");
@@ -306,7 +310,7 @@ extern "C" int orn_stem_bwd(const float *embed, const float *w1, const float *pr
     ORN_REQUIRE(embed && w1 && pre1 && h1 && pre2 && dh2 && dw0 && db0 && dw1 && db1 && ws, "stem_bwd: null pointer");
     ORN_REQUIRE(B > 0 && E > 0 && Hd > 0 && Nout > 0, "stem_bwd: bad sizes");
     return orn_launch_stem_bwd(embed, nullptr, 0, w1, pre1, h1, pre2, dh2, B, E, Hd, Nout, dw0, db0, dw1, db1, ws,
-                               (hipStream_t)stream, 1);
+                               (hipStream_t)stream, 1, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------

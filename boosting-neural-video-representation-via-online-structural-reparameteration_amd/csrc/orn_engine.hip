@@ -426,6 +426,13 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         } else
         ORN_TRY(orn_launch_conv_bwd_f32(x, b.wf, b.z, b.da, 1, l.C, l.O, l.H, l.W, l.s, dx, G + l.w3x3, G + l.b3x3, e->scratch, st));
     }
+    // stem backward; with a wgrad batch behind it, its last kernel (needed by Adam only) rides along that launch
+    OrnStemW0Job w0job;
+    const bool defer_w0 = ff < nl;
+    ORN_TRY(orn_launch_stem_bwd(embeds, fidx, d.embed_len, P + d.stem_w1, e->pre1, e->h1, e->pre2,
+                                e->stage0 ? e->scratch + e->stem_ws : e->dh2, 1, d.embed_len, d.stem_dim, Nout, G + d.stem_w0,
+                                G + d.stem_b0, G + d.stem_w1, G + d.stem_b1, e->scratch, st,
+                                e->stage0 ? orn_stage0_slabs(d.layer[0].O, d.layer[0].s) : 1, defer_w0 ? &w0job : nullptr));
     if (ff < nl) {
         // Weight gradients of every fast layer: nothing on the dgrad chain needs them, so they run here as ONE launch (the
         // small layers' 72 / 216 / 360 work-groups pack behind the last block's 504 instead of leaving CUs idle one launch
@@ -437,7 +444,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
             wj[nj++] = OrnWgradJob{e->L[i].xpad, e->L[i].dypad, l.H, l.W, l.C, l.O, l.s, e->L[i].wslab};
         }
         const OrnHeadFinish hf = {e->head_ws, e->ops->head_bwd_blocks(e->Hout, e->Wout), e->Cn_last, 1.0f / e->gs, G + d.head_w, G + d.head_b};
-        ORN_TRY(e->ops->wgrad_batch(nj, wj, st, &hf));
+        ORN_TRY(e->ops->wgrad_batch(nj, wj, st, &hf, &w0job));
         OrnWgradReduce wr[ORN_MAX_LAYERS];
         for (int i = ff; i < nl; ++i) {
             const orn_layer_desc &l = d.layer[i];
@@ -465,11 +472,6 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         }
         ORN_TRY(orn_launch_merge_bwd_tail_all(nl, mm, st));
     }
-    // fused first block: dh2 arrives as its per-work-group partial rows (behind the stem's own scratch), summed by the stem kernel
-    ORN_TRY(orn_launch_stem_bwd(embeds, fidx, d.embed_len, P + d.stem_w1, e->pre1, e->h1, e->pre2,
-                                e->stage0 ? e->scratch + e->stem_ws : e->dh2, 1, d.embed_len, d.stem_dim, Nout, G + d.stem_w0,
-                                G + d.stem_b0, G + d.stem_w1, G + d.stem_b1, e->scratch, st,
-                                e->stage0 ? orn_stage0_slabs(d.layer[0].O, d.layer[0].s) : 1));
     ORN_TRY(orn_launch_adam(P, G, e->m, e->v, (size_t)d.n_params, 0.0, 1, e->cur, d.beta1, d.beta2, d.eps, 1.0f, st, e->gmask));
     return 0;
 }
