@@ -3,11 +3,13 @@
 // The block that follows the stem works on a 9 x 16 image (0.04 GF of the 202 GF forward) and stays in fp32.  Run through
 // the general fp32 kernels it cost 26 us forward (conv + layout hand-off) and 50 us backward (eight launches: layout
 // hand-off, SiLU'/unshuffle, two split-K GEMMs and their reductions, weight flip, dgrad) -- 5 % of the 720p step, all of
-// it launch floors and exposed latencies.  Here the whole image, a 16-channel slice of the merged kernel and the
-// gradient slice live in LDS, one work-group per 16 output channels, `v_mfma_f32_16x16x4_f32` for the three GEMMs:
-//   forward : conv3x3 + bias + PixelShuffle + SiLU, written straight into the next block's 16-bit channels-last input
-//   backward: sum of the next block's fp32 dgrad slabs x SiLU'(z) (un-shuffled), dbias, dW (no split-K: K = H*W pixels),
-//             and this slice's share of dx (summed over work-groups by orn_launch_reduce_rows, fixed order).
+// it launch floors and exposed latencies.  Here the whole image, a 16-row slice of the merged kernel and of the gradient
+// live in LDS, `v_mfma_f32_16x16x4_f32` for the three GEMMs:
+//   forward : one work-group per 16 consecutive conv channels; conv3x3 + bias + PixelShuffle + SiLU, written straight into
+//             the next block's 16-bit channels-last input; z kept as [sub-position][pixel][channel] for the backward
+//   backward: one work-group per (PixelShuffle sub-position, 16 post-shuffle channels): sum of the next block's fp32 dgrad
+//             slabs x SiLU'(z) (both contiguous per pixel in that split), dbias, dW (no split-K: K = H*W pixels) and the
+//             group's share of dx, left as per-work-group slabs that the stem's first backward kernel sums (fixed order).
 // fp32 products and accumulation throughout (same arithmetic class as the kernels it replaces; summation order differs).
 #include "orn_internal.h"
 
@@ -27,7 +29,7 @@ struct Stage0P {
     const float *x;      // [C][H][W] block input (stem output)
     const float *wf;     // [O][C][3][3] merged kernel
     const float *bf;     // [O]
-    int C, C4, C16, O, H, W, s;
+    int C, C16, O, H, W, s;         // C16: C rounded up to 16 (LDS images are zero-padded to it)
     unsigned mXP, mXW, mWN, mC16, mW, mSS, mS;   // exact division by multiply-high (s0_div): a runtime integer division is ~40
                                                  // VALU instructions, and the LDS fills did ~100 of them per thread (10 of 15 us)
     float *z;            // [s*s][H*W][O/s^2] pre-activation (layout private to this file); null: not kept (decode)
@@ -296,7 +298,7 @@ __global__ void __launch_bounds__(1024) k_stage0_bwd(Stage0P p)
     S0_STAMP(13);
 }
 
-size_t smem_bytes(int C4, int C16, int H, int W, bool bwd)
+size_t smem_bytes(int C16, int H, int W, bool bwd)
 {
     const size_t XP = (size_t)(H + 2) * (W + 2);
     return (C16 * XP + 16 * (size_t)(9 * C16 + 4) + (bwd ? 16 * XP : 0)) * sizeof(float);
@@ -309,7 +311,7 @@ int fill(Stage0P &p, const float *x, const float *wf, const float *bf, int C, in
     auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned long long)d - 1) / (unsigned long long)d); };
     p.mXP = magic((H + 2) * (W + 2)); p.mXW = magic(W + 2); p.mWN = magic(9 * ((C + 15) / 16 * 16) + 4);
     p.mC16 = magic((C + 15) / 16 * 16); p.mW = magic(W); p.mSS = magic(s * s); p.mS = magic(s);
-    p.x = x; p.wf = wf; p.bf = bf; p.C = C; p.C4 = (C + 3) / 4 * 4; p.C16 = (C + 15) / 16 * 16; p.O = O; p.H = H; p.W = W; p.s = s;
+    p.x = x; p.wf = wf; p.bf = bf; p.C = C; p.C16 = (C + 15) / 16 * 16; p.O = O; p.H = H; p.W = W; p.s = s;
     return 0;
 }
 
@@ -328,7 +330,7 @@ int set_smem(K kern, size_t bytes)
 bool orn_stage0_supported(int C, int O, int H, int W, int s)
 {
     return C >= 1 && C <= 64 && O >= 1 && s >= 1 && O % (s * s) == 0 && W >= 4 && H * W <= 256 && (H * W) % 16 == 0 &&
-           smem_bytes((C + 3) / 4 * 4, (C + 15) / 16 * 16, H, W, true) <= 160 * 1024;
+           smem_bytes((C + 15) / 16 * 16, H, W, true) <= 160 * 1024;
 }
 
 // backward work-groups (= dx partial slabs): sub-positions x groups of 16 post-shuffle channels
@@ -342,7 +344,7 @@ int orn_launch_stage0_fwd(const float *x, const float *wf, const float *bf, int 
     ORN_TRY(fill(p, x, wf, bf, C, O, H, W, s));
     ORN_REQUIRE(xpad_next && O / (s * s) <= Cp && (precision == 1 || precision == 2), "stage0_fwd: bad output arguments");
     p.z = z; p.xpad_next = xpad_next; p.Cp = Cp;
-    const size_t smem = smem_bytes(p.C4, p.C16, H, W, false);
+    const size_t smem = smem_bytes(p.C16, H, W, false);
     const dim3 grid(orn_cdiv(O, 16)), block(orn_cdiv(H * W, 16) * 64);
     if (precision == 2) {
         ORN_TRY(set_smem(k_stage0_fwd<_Float16>, smem));
@@ -365,7 +367,7 @@ int orn_launch_stage0_bwd(const float *x, const float *wf, const float *z, const
     ORN_TRY(fill(p, x, wf, nullptr, C, O, H, W, s));
     ORN_REQUIRE(z && dxn && nslab >= 1 && slabs && dwf && dbf, "stage0_bwd: null pointer");
     p.z = const_cast<float *>(z); p.dxn = dxn; p.nslab = nslab; p.Cp = Cp; p.inv_gs = inv_gs; p.dwf = dwf; p.dbf = dbf; p.dx_slabs = slabs;
-    const size_t smem = smem_bytes(p.C4, p.C16, H, W, true);
+    const size_t smem = smem_bytes(p.C16, H, W, true);
     ORN_TRY(set_smem(k_stage0_bwd, smem));
     const int nwg = orn_stage0_slabs(O, s);
     hipLaunchKernelGGL(k_stage0_bwd, dim3(nwg), dim3(orn_cdiv(H * W, 16) * 64), smem, st, p);
