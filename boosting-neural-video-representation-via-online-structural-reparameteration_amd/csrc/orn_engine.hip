@@ -172,7 +172,7 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
     if (s3 > scratch) scratch = s3;
     float *scr = take(scratch);
     float *head_ws = (ff < d->n_layers) ? take(orn_half_ops_bf16()->head_bwd_ws_floats(Cn)) : nullptr;
-    float *cur = take(16);
+    float *cur = take((sizeof(OrnStepCur) * ORN_GRAPH_UNROLL + 3) / 4 + 16);    // one cursor state per step of the unrolled graph
     float *mtab = d->erb ? take(orn_merge_group_bytes() / 4) : nullptr;
     float *mhtab = (d->erb && d->precision != 0) ? take(orn_merge_h16_table_bytes() / 4) : nullptr;
     if (e) {
@@ -299,11 +299,15 @@ extern "C" int orn_engine_fused_kernel(orn_engine *e, int layer, const float **w
 }
 
 // ------------------------------------------------------------------------------------------------
+// `count` consecutive steps at once (thread j -> cur[j]): the unrolled graph advances once for all its steps
 __global__ void k_advance(const orn_step_sched *__restrict__ sched, int32_t *cursor, int32_t n_slots, double beta1,
-                          double beta2, OrnStepCur *cur)
+                          double beta2, OrnStepCur *cur_all, int count)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const int32_t c = *cursor;
+    const int32_t c0 = *cursor;
+    __syncthreads();
+    if (blockIdx.x == 0 && (int)threadIdx.x < count) {
+        const int32_t c = c0 + threadIdx.x;
+        OrnStepCur *cur = cur_all + threadIdx.x;
         const orn_step_sched s = sched[c];
         cur->frame = s.frame;
         cur->step = s.step;
@@ -313,7 +317,7 @@ __global__ void k_advance(const orn_step_sched *__restrict__ sched, int32_t *cur
         cur->step_size = (float)((double)s.lr / bc1);
         cur->sqrt_bc2 = (float)sqrt(bc2);
         cur->slot = n_slots > 0 ? c % n_slots : 0;
-        *cursor = c + 1;
+        if (threadIdx.x == 0) *cursor = c0 + count;
     }
 }
 
@@ -380,19 +384,24 @@ extern "C" int orn_engine_decode(orn_engine *e, const float *embed, float *img, 
     return 0;
 }
 
+// adv_count > 0: advance the device-side schedule by that many steps first (states e->cur[0 .. adv_count)); the step itself
+// runs on e->cur[cur_idx]
 static int train_step(orn_engine *e, const float *frames, const float *embeds, const orn_step_sched *sched,
-                      int32_t *cursor, float *stats_out, int32_t n_slots, hipStream_t st)
+                      int32_t *cursor, float *stats_out, int32_t n_slots, hipStream_t st, int adv_count = 1, int cur_idx = 0)
 {
     const orn_engine_desc &d = e->d;
     float *P = e->params, *G = e->grads;
     const int Nout = d.fc_h * d.fc_w * d.fc_dim;
     const size_t HWo = (size_t)e->Hout * e->Wout;
-    hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, sched, cursor, n_slots, d.beta1, d.beta2, e->cur);
-    ORN_LAUNCH_CHECK("advance");
-    const int *fidx = &e->cur->frame;
+    OrnStepCur *cur = e->cur + cur_idx;
+    if (adv_count > 0) {
+        hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, sched, cursor, n_slots, d.beta1, d.beta2, e->cur, adv_count);
+        ORN_LAUNCH_CHECK("advance");
+    }
+    const int *fidx = &cur->frame;
     ORN_TRY(forward(e, embeds, fidx, true, st));
     ORN_TRY(orn_launch_loss(e->img, frames, fidx, 3 * HWo, 1, 3, e->Hout, e->Wout, d.loss_type, 1.0f, e->stats, e->dimg,
-                            e->loss_ws, st, e->cur, stats_out));
+                            e->loss_ws, st, cur, stats_out));
     const int nl = d.n_layers, ff = e->ff;
     if (ff < nl)
         ORN_TRY(e->ops->head_bwd(e->L[nl - 1].zb, P + d.head_w, e->img, e->dimg, e->Cn_last, e->Hout, e->Wout, d.sigmoid,
@@ -472,7 +481,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         }
         ORN_TRY(orn_launch_merge_bwd_tail_all(nl, mm, st));
     }
-    ORN_TRY(orn_launch_adam(P, G, e->m, e->v, (size_t)d.n_params, 0.0, 1, e->cur, d.beta1, d.beta2, d.eps, 1.0f, st, e->gmask));
+    ORN_TRY(orn_launch_adam(P, G, e->m, e->v, (size_t)d.n_params, 0.0, 1, cur, d.beta1, d.beta2, d.eps, 1.0f, st, e->gmask));
     return 0;
 }
 
@@ -535,7 +544,7 @@ extern "C" int orn_engine_train_steps_graph(orn_engine *e, const float *frames, 
             hipError_t rc = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
             if (rc != hipSuccess) { orn_set_error("graph: BeginCapture failed: %s", hipGetErrorString(rc)); return (int)rc; }
             int trc = 0;
-            for (int r = 0; r < reps && trc == 0; ++r) trc = train_step(e, frames, embeds, sched, cursor, stats_out, n_slots, st);
+            for (int r = 0; r < reps && trc == 0; ++r) trc = train_step(e, frames, embeds, sched, cursor, stats_out, n_slots, st, r == 0 ? reps : 0, r);
             rc = hipStreamEndCapture(st, g);
             if (trc != 0) { if (*g) { (void)hipGraphDestroy(*g); *g = nullptr; } return trc; }
             if (rc != hipSuccess) { orn_set_error("graph: EndCapture failed: %s", hipGetErrorString(rc)); return (int)rc; }
