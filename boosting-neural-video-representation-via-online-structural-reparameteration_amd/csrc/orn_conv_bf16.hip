@@ -17,6 +17,7 @@
 // This file is compiled twice: as is (bf16, namespace orn_bf16) and with -DORN_FP16 (IEEE half, namespace
 // orn_f16: 11-bit significand, same MFMA rate; gradients then travel scaled by 2^20, see the engine).
 #include "orn_internal.h"
+#include <type_traits>
 #ifdef ORN_FP16
 #define HNS orn_f16
 typedef _Float16 h16;
@@ -31,6 +32,16 @@ typedef __attribute__((ext_vector_type(4))) h16 h16x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N)
+template <int I, int N, class F>
+__device__ __forceinline__ void orn_sfor(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        orn_sfor<I + 1, N>(f);
+    }
+}
 
 namespace HNS {
 
@@ -107,6 +118,46 @@ struct ConvBP {
     int dbg;             // timing-only ablation flags (tools/probes): 1 no weight restage, 2 no patch stage, 4 no stores
 };
 
+// Fragment reads of k-step (TAP, KS_) into register set SET: MB patch rows (the MFMA's B operand: pixels) and NB weight
+// blocks (A operand: output channels).  a_lane = LDS byte address of this lane's patch pixel for (row wm*MB, tap 0),
+// pix_lane = that pixel's index (for the swizzle), b_par0 = this lane's weight-row address for k-step parity 0.
+template <int MB, int NB, int ROWB, int BS_BYTES, bool ALLTAPS, int SET, int TAP, int KS_>
+__device__ __forceinline__ void conv_read_step(h16x8 (&fa)[2][MB], h16x8 (&fb)[2][NB], unsigned a_lane, unsigned pix_lane, unsigned b_par0, int hh)
+{
+    constexpr int ti = TAP / 3, tj = TAP - ti * 3, par = KS_ & 1;
+    constexpr int buf = ALLTAPS ? TAP : TAP % 3;
+    constexpr int kimm = 64 * (KS_ >> 1);
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const unsigned pixoff = (i + ti) * CB_PW + tj;
+        const unsigned pix = pix_lane + pixoff;
+        const unsigned addr = a_lane + pixoff * ROWB + 16 * ((2 * par + hh) ^ ((pix >> 2) & 3));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[SET][i]) : "v"(addr), "n"(kimm) : "memory");
+    }
+    const unsigned baddr = (b_par0 ^ (32 * par)) + (buf >= 4 ? 4 * BS_BYTES : 0);
+    constexpr int bimm = (buf >= 4 ? buf - 4 : buf) * BS_BYTES + kimm;
+    static_assert(bimm + (NB - 1) * 32 * ROWB < 65536, "ds_read offset field");
+    static_assert(NB <= 3, "conv_read_step: add the fourth weight block");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[SET][0]) : "v"(baddr), "n"(bimm) : "memory");
+    if constexpr (NB > 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[SET][NB > 1 ? 1 : 0]) : "v"(baddr), "n"(bimm + 32 * ROWB) : "memory");
+    if constexpr (NB > 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[SET][NB > 2 ? 2 : 0]) : "v"(baddr), "n"(bimm + 64 * ROWB) : "memory");
+}
+
+// The wait that retires register set SET (its reads were issued before the PEND newest ones) names every register of the
+// set as read-write, so no MFMA that consumes them can be scheduled above it.
+template <int MB, int NB, int SET, int PEND>
+__device__ __forceinline__ void conv_wait_set(h16x8 (&fa)[2][MB], h16x8 (&fb)[2][NB])
+{
+    if constexpr (MB == 2 && NB == 2)
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa[SET][0]), "+v"(fa[SET][MB > 1 ? 1 : 0]), "+v"(fb[SET][0]), "+v"(fb[SET][NB > 1 ? 1 : 0]) : "n"(PEND));
+    else if constexpr (MB == 1 && NB == 3)
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa[SET][0]), "+v"(fb[SET][0]), "+v"(fb[SET][NB > 1 ? 1 : 0]), "+v"(fb[SET][NB > 2 ? 2 : 0]) : "n"(PEND));
+    else if constexpr (MB == 1 && NB == 1)
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fa[SET][0]), "+v"(fb[SET][0]) : "n"(PEND));
+    else
+        static_assert(MB == 2 && NB == 2, "conv_wait_set: add this wave tile");
+}
+
 // CK = input channels per K chunk: 96 (the general form above), or 32 for a layer whose input has <= 32 real channels
 // (the zero-padded narrow layer, forward only): its whole K = 9 x 32 fits LDS -- patch 22 KB + all nine [BN][32] weight
 // tiles 72 KB -- so an N tile is ONE rendezvous and 72 back-to-back MFMAs per wave instead of nine rounds of barrier +
@@ -169,14 +220,14 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
     for (int k = 0; k < B_PER_WAVE; ++k) {
         const int m = (uwave + NWAVES * k) % B_INSTR;              // surplus instructions re-load a tile piece (harmless)
         const int L = m * 64 + lane, R = L / NCH, pos = L - R * NCH;
-        const int c = NARROW ? (pos ^ ((R >> 2) & 3)) : (pos - ((R >> 2) & 3) + 12) % 12;
+        const int c = pos ^ ((R >> 2) & 3);
         b_goff[k] = R * Cin + c * 8;
     }
 #pragma unroll
     for (int k = 0; k < P_PER_WAVE; ++k) {
         const int m = uwave + NWAVES * k;
         const int L = m * 64 + lane, pix = L / NCH, pos = L - pix * NCH;
-        const int c = NARROW ? (pos ^ ((pix >> 2) & 3)) : (pos - ((pix >> 2) & 3) + 12) % 12;
+        const int c = pos ^ ((pix >> 2) & 3);
         const int pr = pix / CB_PW, pc = pix - pr * CB_PW;
         const int gh = h0 + pr, gw_ = w0 + pc;
         p_ok[k] = (pix < CB_PH * CB_PW) && gh < H + 2 && gw_ < W + 2;
@@ -200,19 +251,14 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
     }
 #define WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory")
 #define BARRIER() __builtin_amdgcn_s_barrier()
-    // fragment reads: 16 bytes at logical chunk (2*ks + hh) of a row -> rotated position
-#define CHUNK_OFF(rot_, ks_) (NARROW ? 16 * ((2 * (ks_) + hh) ^ (rot_)) : wrap_row(16 * (hh + (rot_)) + (ks_) * 32))
-#define READ_FRAGS(A_, B_, buf_, ks_)                                                                           \
-    {                                                                                                           \
-        _Pragma("unroll") for (int i = 0; i < MB; ++i)                                                          \
-            A_[i] = *reinterpret_cast<const h16x8 *>(patch + a_row[i] + CHUNK_OFF(a_rot[i], ks_));              \
-        const int ob = CHUNK_OFF(b_rot, ks_);                                                                   \
-        _Pragma("unroll") for (int j = 0; j < NB; ++j)                                                          \
-            B_[j] = *reinterpret_cast<const h16x8 *>(bs0 + (buf_) * BS_BYTES + b_row + j * 32 * ROWB + ob);     \
-    }
-    auto wrap_row = [](int o) { return o - ((o >= ROWB) ? ROWB : 0); };
-    const int b_row = (wn * NB * 32 + l31) * ROWB;
-    const int b_rot = (l31 >> 2) & 3;
+    // Fragment reads are hand-placed (inline asm: hipcc sinks every builtin LDS read next to its consumer and waits
+    // lgkmcnt(0) right behind it, which exposed one LDS round trip per k-step).  16 bytes at logical chunk c = 2*ks + hh of
+    // row R sit at position c ^ ((R >> 2) & 3): byte offset 64*(ks >> 1) [an immediate] + 16*((2*(ks & 1) + hh) ^ rot) [two
+    // per-lane values, one per k-step parity, 32 apart by XOR].  All addresses are LDS byte offsets in a VGPR.
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    const unsigned b_rot = (l31 >> 2) & 3;
+    const unsigned b_par0 = lds0 + PATCH_LDS + (wn * NB * 32 + l31) * ROWB + 16 * (hh ^ b_rot);   // weight rows, parity 0
+    const unsigned a_lane = lds0 + (wm * MB * CB_PW + l31) * ROWB;                               // patch pixel of (row wm*MB, tap 0)
 
     // EPI_B_FWD: the packed outputs of an N tile are stored AFTER the next N tile's prologue rendezvous, so the
     // store drain overlaps the next main loop instead of stalling the prologue's vmcnt(0)
@@ -261,56 +307,53 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
         BARRIER();
         if (!ALLTAPS && n_tiles > 2) DMA_B(2, nt, 0, 2)
         if (EPI_IS_FWD(EPI) && pending) FLUSH_DEFERRED()
+        // One software pipeline over all k-steps of the N tile (chunks of 96 input channels outside; nine taps x CK/16
+        // k-slices inside, unrolled at compile time so tap, kernel row / column, ring slot and LDS offsets are constants):
+        // step s issues the fragment reads of step s+1 into the other register set, waits with a COUNTED lgkmcnt for its
+        // own (issued a whole step earlier), then runs its MFMAs -- also across a tap boundary, so the rendezvous at the end
+        // of a tap sits between MFMAs whose operands are already in registers or in flight.  Reading tile t+1 before
+        // rendezvous t is legal because every wave waits for ALL its outstanding DMA pieces (tile t+2 included) before
+        // rendezvous t: tile t+1 was complete, and known to be, at rendezvous t-1.  Ring: after rendezvous t the DMA of
+        // tile t+3 overwrites tile t.
+        constexpr int KS = CK / 16, NR = MB + NB;
+        static_assert(KS % 2 == 0, "register-set parity must repeat per tap");
         h16x8 fa[2][MB], fb[2][NB];
-        // Chunks of 96 input channels outside, the nine taps inside and fully unrolled: tap, kernel row / column and the
-        // ring slot (tile 9q + tap -> slot tap % 3) fold to constants in every instantiation.
+#define READ_STEP(set_, tap_, ks_) conv_read_step<MB, NB, ROWB, BS_BYTES, ALLTAPS, set_, tap_, ks_>(fa, fb, a_lane, wm * MB * CB_PW + l31, b_par0, hh)
+        READ_STEP(0, 0, 0);
         for (int q = 0; q < Q; ++q) {
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int tt = q * 9 + tap;
-                constexpr int dummy_ = 0; (void)dummy_;
-                const int buf = ALLTAPS ? tap : tap % 3;
-                const int ti = tap / 3, tj = tap - ti * 3;
-                const bool last_chunk = (q + 1 >= Q);
-                const bool has_next = (tap < 8) || !last_chunk;
-                const bool same_chunk = (tap < 8);
-                int a_row[MB], a_rot[MB];
-#pragma unroll
-                for (int i = 0; i < MB; ++i) {
-                    const int pix = (wm * MB + i + ti) * CB_PW + l31 + tj;
-                    a_row[i] = pix * ROWB;
-                    a_rot[i] = (pix >> 2) & 3;
-                }
-                READ_FRAGS(fa[0], fb[0], buf, 0)
-#pragma unroll
-                for (int ks = 0; ks < CK / 16; ++ks) {
-                    if (ks + 1 < CK / 16 && !(PDBG(p) & 16)) READ_FRAGS(fa[(ks + 1) & 1], fb[(ks + 1) & 1], buf, ks + 1)
+            const bool last_chunk = (q + 1 >= Q);
+            orn_sfor<0, 9>([&](auto tap_c) __attribute__((always_inline)) {
+                constexpr int tap = decltype(tap_c)::value;
+                constexpr int buf = ALLTAPS ? tap : tap % 3;
+                orn_sfor<0, KS>([&](auto ks_c) __attribute__((always_inline)) {
+                    constexpr int ks = decltype(ks_c)::value;
+                    constexpr int cur = ks & 1;
+                    constexpr bool more = (ks + 1 < KS) || (tap < 8);
+                    if constexpr (ks + 1 < KS) READ_STEP(cur ^ 1, tap, ks + 1);
+                    else if constexpr (tap < 8) READ_STEP(0, tap + 1, 0);
+                    conv_wait_set<MB, NB, cur, (more ? NR : 0)>(fa, fb);
 #pragma unroll
                     for (int i = 0; i < MB; ++i)
 #pragma unroll
-                        for (int j = 0; j < NB; ++j) acc[i][j] = MFMA_H16(fb[ks & 1][j], fa[ks & 1][i], acc[i][j]);
-                }
-                if (!ALLTAPS && has_next) {
-                    // tile tt+1 was issued two tiles ago: let only tile tt+2's DMA stay in flight, then rendezvous
-                    if (tap < 7 || !last_chunk) {
-                        if (B_PER_WAVE == 6) WAIT_VM(6); else if (B_PER_WAVE == 5) WAIT_VM(5); else if (B_PER_WAVE == 4) WAIT_VM(4);
-                        else if (B_PER_WAVE == 3) WAIT_VM(3); else WAIT_VM(2);
-                    }
-                    else WAIT_VM(0);
+                        for (int j = 0; j < NB; ++j) acc[i][j] = MFMA_H16(fb[cur][j], fa[cur][i], acc[i][j]);
+                });
+                if (!ALLTAPS && ((tap < 8) || !last_chunk)) {
+                    WAIT_VM(0);                     // this wave's pieces of every tile in flight (tile tt+2) have landed
                     if (!(PDBG(p) & 8)) BARRIER();
-                    if (!same_chunk) {              // everyone is done with the old chunk's patch
+                    if constexpr (tap == 8) {       // next chunk: everyone is done with the old chunk's patch
                         if (!(PDBG(p) & 2)) DMA_PATCH(q + 1)
                         WAIT_VM(0);
                         BARRIER();
                     }
                     if (!(PDBG(p) & 1)) {           // tile tt + 3 into the buffer of tile tt (free now)
-                        if (tap < 6) DMA_B(buf, nt, q, tap + 3)
+                        if constexpr (tap < 6) DMA_B(buf, nt, q, tap + 3)
                         else if (!last_chunk) DMA_B(buf, nt, q + 1, tap - 6)
                     }
+                    if constexpr (tap == 8) READ_STEP(0, 0, 0);
                 }
-                (void)tt;
-            }
+            });
         }
+#undef READ_STEP
 
         // ---- epilogue --------------------------------------------------------------------------
         // Lane (pixel l31, half hh) holds channels 8g + 4hh + e (g = reg>>2, e = reg&3) of each 32-ch block.
@@ -393,8 +436,6 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
 #undef DMA_PATCH
 #undef WAIT_VM
 #undef BARRIER
-#undef READ_FRAGS
-#undef CHUNK_OFF
 
 template <int WAVES_M, int WAVES_N, int MB, int NB, int EPI, int CK = CB_CK, bool ALLTAPS = (CK != CB_CK)>
 static int launch_conv_cfg(const ConvBP &p, int n_tiles_total, hipStream_t st)
