@@ -6,8 +6,12 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-OBJ = os.path.join(HERE, 'build')
-LIB = os.path.join(HERE, 'liborn.so')
+# ORN_BUILD_TAG=<tag> (+ ORN_EXTRA_DEFS="-DX -DY"): a diagnostic variant next to the product library, build_<tag>/ ->
+# liborn_<tag>.so, picked up by tools/probes through ORN_LIB_PATH.  The product build uses neither.
+TAG = os.environ.get('ORN_BUILD_TAG', '')
+OBJ = os.path.join(HERE, 'build' + ('_' + TAG if TAG else ''))
+LIB = os.path.join(HERE, 'liborn' + ('_' + TAG if TAG else '') + '.so')
+EXTRA = os.environ.get('ORN_EXTRA_DEFS', '').split() if TAG else []
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 
@@ -42,7 +46,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         s, o, extra = job
         # ORN_CONV_ABLATE=1 (with force=True): timing-ablation flags of the conv kernels for tools/probes/*_ablate.py
         abl = ['-DORN_CONV_ABLATE'] if os.environ.get('ORN_CONV_ABLATE') == '1' else []
-        cmd = [HIPCC] + FLAGS + extra + abl + ['-c', s, '-o', o]
+        cmd = [HIPCC] + FLAGS + extra + abl + EXTRA + ['-c', s, '-o', o]
         if verbose:
             print(' '.join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

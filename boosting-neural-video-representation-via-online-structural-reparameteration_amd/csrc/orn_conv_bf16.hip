@@ -53,6 +53,26 @@ namespace HNS {
 #define PDBG(p_) 0
 #endif
 static int g_conv_dbg = 0;   // timing experiments only (tools/probes), see orn_debug_set
+// Phase stamps (diagnostic build -DORN_CONV_STAMP; the product build compiles none of it): wave 0 of every work-group writes
+// s_memtime at the N-tile phase boundaries into a buffer no other code reads.
+#ifdef ORN_CONV_STAMP
+static unsigned long long *g_conv_stamps = nullptr;
+// stamps collect in 512 B of LDS behind the kernel's own images (a global store per stamp would sit in every vmcnt wait)
+#define STAMP_LDS ((unsigned long long *)(smem + PATCH_LDS + NBUF * BS_BYTES + (EPI_IS_FWD(EPI) ? ((p.Nout * 4 + 255) & ~255) : 0)))
+#define STAMP(i_) { if (p.stamps && t == 0) STAMP_LDS[i_] = __builtin_amdgcn_s_memtime(); }
+#define STAMP_RT(i_) { if (p.stamps && t == 0) STAMP_LDS[i_] = __builtin_amdgcn_s_memrealtime(); }
+#define STAMP_FLUSH() { if (p.stamps && t < 128) p.stamps[(size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 128 + t] = STAMP_LDS[t]; }
+// per-tap stamps of wave 0 (slots 16..) and of the wave that shares its SIMD (slots 64..): up to 4 N tiles / chunks x 9 taps
+#define STAMP_TAP(seg_, tap_) { if (p.stamps && (seg_) < 4 && lane == 0 && (wave == 0 || wave == NWAVES / 2)) STAMP_LDS[(wave == 0 ? 16 : 64) + (seg_) * 9 + (tap_)] = __builtin_amdgcn_s_memtime(); }
+// rendezvous of taps 3..5 of segment 0: arrival (k 0), after the vmcnt wait (1), after the barrier (2); wave 0 -> slots 100.., partner -> 112..
+#define STAMP_BAR(seg_, tap_, k_) { if (p.stamps && (seg_) == 0 && (tap_) >= 3 && (tap_) <= 5 && lane == 0 && (wave == 0 || wave == NWAVES / 2)) STAMP_LDS[(wave == 0 ? 100 : 112) + ((tap_) - 3) * 3 + (k_)] = __builtin_amdgcn_s_memtime(); }
+#else
+#define STAMP(i_)
+#define STAMP_RT(i_)
+#define STAMP_FLUSH()
+#define STAMP_TAP(seg_, tap_)
+#define STAMP_BAR(seg_, tap_, k_)
+#endif
 
 #define CB_TH 8
 #define CB_TW 32
@@ -106,6 +126,7 @@ struct ConvBP {
     h16 *z;              // [H*s][W*s][Cn]
     h16 *apad;           // [H*s+2][W*s+2][Cn] or null
     int s, Cn;
+    unsigned z_bytes, apad_bytes;   // sizes of the two buffers (raw-buffer bounds)
     // EPI_B_DGRAD: out = dx * silu'(zprev) scattered into the previous layer's dypad
     const h16 *zprev;    // [H][W][Nout]
     h16 *dyprev;         // [H/sp+2][W/sp+2][Nout*sp*sp]
@@ -116,13 +137,21 @@ struct ConvBP {
     // and 16 of them per N tile per lane were a measurable part of the forward kernel): conv_div / conv_magic
     unsigned mCn, mS, mSp;
     int dbg;             // timing-only ablation flags (tools/probes): 1 no weight restage, 2 no patch stage, 4 no stores
+    unsigned long long *stamps;   // -DORN_CONV_STAMP diagnostic builds only: 64 time stamps per work-group (tools/probes/conv_stamps.py)
 };
 
+// Fragment register sets: reads run CONV_NSET - 1 k-steps ahead of the MFMAs that consume them
+#ifndef CONV_NSET_FWD
+#define CONV_NSET_FWD 2
+#endif
+#ifndef CONV_NSET_DGRAD
+#define CONV_NSET_DGRAD 2
+#endif
 // Fragment reads of k-step (TAP, KS_) into register set SET: MB patch rows (the MFMA's B operand: pixels) and NB weight
 // blocks (A operand: output channels).  a_lane = LDS byte address of this lane's patch pixel for (row wm*MB, tap 0),
 // pix_lane = that pixel's index (for the swizzle), b_par0 = this lane's weight-row address for k-step parity 0.
-template <int MB, int NB, int ROWB, int BS_BYTES, bool ALLTAPS, int SET, int TAP, int KS_>
-__device__ __forceinline__ void conv_read_step(h16x8 (&fa)[2][MB], h16x8 (&fb)[2][NB], unsigned a_lane, unsigned pix_lane, unsigned b_par0, int hh)
+template <int NSET, int MB, int NB, int ROWB, int BS_BYTES, bool ALLTAPS, int SET, int TAP, int KS_>
+__device__ __forceinline__ void conv_read_step(h16x8 (&fa)[NSET][MB], h16x8 (&fb)[NSET][NB], unsigned a_lane, unsigned pix_lane, unsigned b_par0, int hh)
 {
     constexpr int ti = TAP / 3, tj = TAP - ti * 3, par = KS_ & 1;
     constexpr int buf = ALLTAPS ? TAP : TAP % 3;
@@ -145,8 +174,8 @@ __device__ __forceinline__ void conv_read_step(h16x8 (&fa)[2][MB], h16x8 (&fb)[2
 
 // The wait that retires register set SET (its reads were issued before the PEND newest ones) names every register of the
 // set as read-write, so no MFMA that consumes them can be scheduled above it.
-template <int MB, int NB, int SET, int PEND>
-__device__ __forceinline__ void conv_wait_set(h16x8 (&fa)[2][MB], h16x8 (&fb)[2][NB])
+template <int NSET, int MB, int NB, int SET, int PEND>
+__device__ __forceinline__ void conv_wait_set(h16x8 (&fa)[NSET][MB], h16x8 (&fb)[NSET][NB])
 {
     if constexpr (MB == 2 && NB == 2)
         asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa[SET][0]), "+v"(fa[SET][MB > 1 ? 1 : 0]), "+v"(fb[SET][0]), "+v"(fb[SET][NB > 1 ? 1 : 0]) : "n"(PEND));
@@ -186,7 +215,16 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
     constexpr int PATCH_LDS = PATCH_INSTR * 1024;
     constexpr int BS_BYTES = BN * ROWB;
     constexpr int B_INSTR = BS_BYTES / 1024;           // wave-instructions per weight tile
-    constexpr int B_PER_WAVE = (B_INSTR + NWAVES - 1) / NWAVES;
+    // Weight tiles are fetched by the FIRST HALF of the waves only (one per SIMD: waves w and w + NWAVES/2 share one): an
+    // LDS-DMA instruction parks its wave for ~100 cycles, and when both waves of a SIMD issue theirs right after the
+    // rendezvous the matrix pipe idles for all of them (~300 cycles per tap, measured with phase stamps); with one loader
+    // per SIMD its partner's MFMAs run meanwhile, and the loader catches up while the partner waits at the next rendezvous.
+#ifdef ORN_DGRAD_ALL_LOAD
+    constexpr int NLOAD = (ALLTAPS || NWAVES < 8 || !EPI_IS_FWD(EPI)) ? NWAVES : NWAVES / 2;
+#else
+    constexpr int NLOAD = (ALLTAPS || NWAVES < 8) ? NWAVES : NWAVES / 2;
+#endif
+    constexpr int B_PER_WAVE = (B_INSTR + NLOAD - 1) / NLOAD;
     constexpr int P_PER_WAVE = (PATCH_INSTR + NWAVES - 1) / NWAVES;
     static_assert((NARROW || PATCH_INSTR % NWAVES == 0) && BS_BYTES % 1024 == 0, "tile geometry");
     unsigned char *patch = smem;
@@ -218,7 +256,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
     bool p_ok[P_PER_WAVE];
 #pragma unroll
     for (int k = 0; k < B_PER_WAVE; ++k) {
-        const int m = (uwave + NWAVES * k) % B_INSTR;              // surplus instructions re-load a tile piece (harmless)
+        const int m = (uwave + NLOAD * k) % B_INSTR;               // surplus instructions re-load a tile piece (harmless)
         const int L = m * 64 + lane, R = L / NCH, pos = L - R * NCH;
         const int c = pos ^ ((R >> 2) & 3);
         b_goff[k] = R * Cin + c * 8;
@@ -239,9 +277,11 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
                                      (__attribute__((address_space(3))) void *)(smem + (ldsoff_)), 16, 0, 0)
 #define DMA_B(buf_, nt_, q_, tap_)                                                                              \
     {                                                                                                           \
-        const h16 *wbase = p.w + ((size_t)((tap_) * p.Nout + (nt_) * BN) * Cin + ((q_) + q_base) * CK);         \
-        _Pragma("unroll") for (int k = 0; k < B_PER_WAVE; ++k)                                                  \
-            DMA16(wbase + b_goff[k], PATCH_LDS + (buf_) * BS_BYTES + ((uwave + NWAVES * k) % B_INSTR) * 1024);  \
+        if (NLOAD == NWAVES || uwave < NLOAD) {                                                                 \
+            const h16 *wbase = p.w + ((size_t)((tap_) * p.Nout + (nt_) * BN) * Cin + ((q_) + q_base) * CK);     \
+            _Pragma("unroll") for (int k = 0; k < B_PER_WAVE; ++k)                                              \
+                DMA16(wbase + b_goff[k], PATCH_LDS + (buf_) * BS_BYTES + ((uwave + NLOAD * k) % B_INSTR) * 1024); \
+        }                                                                                                       \
     }
 #define DMA_PATCH(q_)                                                                                           \
     {                                                                                                           \
@@ -250,6 +290,7 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
                 DMA16(p.xpad + p_goff[k] + (p_ok[k] ? ((q_) + q_base) * CK : 0), (uwave + NWAVES * k) * 1024);  \
     }
 #define WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory")
+#define WAIT_VMC(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
 #define BARRIER() __builtin_amdgcn_s_barrier()
     // Fragment reads are hand-placed (inline asm: hipcc sinks every builtin LDS read next to its consumer and waits
     // lgkmcnt(0) right behind it, which exposed one LDS round trip per k-step).  16 bytes at logical chunk c = 2*ks + hh of
@@ -260,29 +301,28 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
     const unsigned b_par0 = lds0 + PATCH_LDS + (wn * NB * 32 + l31) * ROWB + 16 * (hh ^ b_rot);   // weight rows, parity 0
     const unsigned a_lane = lds0 + (wm * MB * CB_PW + l31) * ROWB;                               // patch pixel of (row wm*MB, tap 0)
 
-    // EPI_B_FWD: the packed outputs of an N tile are stored AFTER the next N tile's prologue rendezvous, so the
-    // store drain overlaps the next main loop instead of stalling the prologue's vmcnt(0)
-    constexpr bool APAD = (EPI == EPI_B_FWD);          // writes a = SiLU(z) into the next layer's padded input
-    constexpr int NDEF = EPI_IS_FWD(EPI) ? MB * NB * 2 : 1;
-    u32x4 dz[NDEF], da[NDEF];
-    int dzo[NDEF], dao[NDEF];
-    bool dok[NDEF];
-    bool pending = false;
-#define FLUSH_DEFERRED()                                                                                        \
-    {                                                                                                           \
-        _Pragma("unroll") for (int e_ = 0; e_ < NDEF; ++e_) {                                                   \
-            if (dok[e_]) {                                                                                      \
-                *reinterpret_cast<u32x4 *>(p.z + dzo[e_]) = dz[e_];                                             \
-                if (APAD) *reinterpret_cast<u32x4 *>(p.apad + dao[e_]) = da[e_];                              \
-            }                                                                                                   \
-        }                                                                                                       \
-        pending = false;                                                                                        \
-    }
+    // EPI_B_FWD*: the packed outputs of an N tile are stored by its epilogue as RAW BUFFER stores that every lane issues
+    // (out-of-image lanes carry an out-of-range offset and are dropped by the bounds check): the number of vector-memory
+    // operations behind the last DMA is then known, and the next rendezvous' wait steps over them (vmcnt(n) = all but the n
+    // newest) instead of stalling on HBM write latency.
+    constexpr bool APAD = (EPI == EPI_B_FWD);          // also writes a = SiLU(z) into the next layer's padded input
+    constexpr int NST = EPI_IS_FWD(EPI) ? MB * NB * 2 * (APAD ? 2 : 1) : 0;   // stores per wave and N tile
+    bool pending = false;                              // epilogue stores were issued after this wave's last DMA wait
+    // z / apad as raw buffers: byte offsets; 0x80000000 (out of range for any buffer the launcher admits) drops the lane's store
+    const auto z_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.z, 0, EPI_IS_FWD(EPI) ? p.z_bytes : 0, 0x00020000);
+    const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.apad, 0, APAD ? p.apad_bytes : 0, 0x00020000);
     float *sbias = reinterpret_cast<float *>(smem + PATCH_LDS + NBUF * BS_BYTES);     // [Nout] after the weight ring (EPI_B_FWD)
     if (EPI_IS_FWD(EPI))
         for (int i = t; i < p.Nout; i += NT) sbias[i] = p.bias ? p.bias[i] : 0.f;   // visible after the first N tile's barriers
+#ifdef ORN_CONV_PRIO
+    if (NLOAD != NWAVES && uwave >= NLOAD) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for the non-loader half
+#endif
+    STAMP_RT(0)
+    constexpr int NSET = EPI_IS_FWD(EPI) ? CONV_NSET_FWD : CONV_NSET_DGRAD, LEAD = NSET - 1;   // reads run LEAD k-steps ahead of their MFMAs
+    h16x8 fa[NSET][MB], fb[NSET][NB];                   // fragment register sets (carried across N tiles by the pipeline)
     for (int nti = 0; nti < nt_cnt; ++nti) {
         const int nt = nt0 + nti;
+        STAMP(2 + nti * 4)
         // acc[i][j]: D rows = 32 output channels (A operand = weights), D cols = 32 pixels of one row
         // (B operand = input patch): each lane owns ONE pixel and 16 channels in groups of 4 consecutive.
         f32x16 acc[MB][NB];
@@ -293,67 +333,96 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        // prologue: every wave is done with the previous N tile's buffers -> DMA the patch (first N tile or
-        // multi-chunk input) and weight tiles 0, 1; tile 2 stays in flight behind the first barrier.
-        BARRIER();
-        if ((nti == 0 || Q > 1) && !(PDBG(p) & 2)) DMA_PATCH(0)
-        DMA_B(0, nt, 0, 0)
-        if (n_tiles > 1) DMA_B(1, nt, 0, 1)
-        if (ALLTAPS) {                                 // the whole K of this N tile: taps 2..8 too, then the only rendezvous
+        // prologue (every N tile of the all-taps-resident forms; otherwise once per work-group: the weight-tile ring then
+        // runs on ACROSS N tiles -- the last three taps of an N tile fetch the first three tiles of the next one, so an N
+        // tile boundary costs a rendezvous, not a drained pipeline): the patch (chunk 0) and weight tiles 0, 1; tile 2 stays
+        // in flight behind the first rendezvous.
+        const bool has_next_nt = (nti + 1 < nt_cnt);
+        if (ALLTAPS || nti == 0) {
+            BARRIER();
+            if ((nti == 0 || Q > 1) && !(PDBG(p) & 2)) DMA_PATCH(0)
+            DMA_B(0, nt, 0, 0)
+            if (n_tiles > 1) DMA_B(1, nt, 0, 1)
+            if (ALLTAPS) {                             // the whole K of this N tile: taps 2..8 too, then the only rendezvous
 #pragma unroll
-            for (int tp = 2; tp < 9; ++tp) DMA_B(tp, nt, 0, tp)
+                for (int tp = 2; tp < 9; ++tp) DMA_B(tp, nt, 0, tp)
+            }
+            WAIT_VM(0);
+            BARRIER();
+            if (!ALLTAPS && n_tiles > 2) DMA_B(2, nt, 0, 2)
         }
-        WAIT_VM(0);
-        BARRIER();
-        if (!ALLTAPS && n_tiles > 2) DMA_B(2, nt, 0, 2)
-        if (EPI_IS_FWD(EPI) && pending) FLUSH_DEFERRED()
-        // One software pipeline over all k-steps of the N tile (chunks of 96 input channels outside; nine taps x CK/16
-        // k-slices inside, unrolled at compile time so tap, kernel row / column, ring slot and LDS offsets are constants):
-        // step s issues the fragment reads of step s+1 into the other register set, waits with a COUNTED lgkmcnt for its
-        // own (issued a whole step earlier), then runs its MFMAs -- also across a tap boundary, so the rendezvous at the end
-        // of a tap sits between MFMAs whose operands are already in registers or in flight.  Reading tile t+1 before
-        // rendezvous t is legal because every wave waits for ALL its outstanding DMA pieces (tile t+2 included) before
-        // rendezvous t: tile t+1 was complete, and known to be, at rendezvous t-1.  Ring: after rendezvous t the DMA of
-        // tile t+3 overwrites tile t.
-        constexpr int KS = CK / 16, NR = MB + NB;
-        static_assert(KS % 2 == 0, "register-set parity must repeat per tap");
-        h16x8 fa[2][MB], fb[2][NB];
-#define READ_STEP(set_, tap_, ks_) conv_read_step<MB, NB, ROWB, BS_BYTES, ALLTAPS, set_, tap_, ks_>(fa, fb, a_lane, wm * MB * CB_PW + l31, b_par0, hh)
-        READ_STEP(0, 0, 0);
+        // One software pipeline over all k-steps (chunks of 96 input channels outside; nine taps x CK/16 k-slices inside,
+        // unrolled at compile time so tap, kernel row / column, ring slot, register set and LDS offsets are constants): step s
+        // issues the fragment reads of step s+LEAD into another register set, waits with a COUNTED lgkmcnt for its own
+        // (issued LEAD steps earlier), then runs its MFMAs -- also across a tap boundary, so the rendezvous at the end of a tap
+        // sits between MFMAs whose operands are already in registers or in flight.  (LEAD = 2 measured the same as 1 on the
+        // 720p shapes: CONV_NSET_* keep the knob.)  Reading tile t+1 before rendezvous t is legal because every wave waits for
+        // ALL its outstanding DMA pieces (tile t+2 included) before rendezvous t: tile t+1 was complete, and known to be, at
+        // rendezvous t-1.  Ring: after rendezvous t the DMA of tile t+3 overwrites tile t.
+        constexpr int KS = CK / 16, NR = MB + NB, NSTEP = 9 * KS;
+        static_assert(NSTEP % NSET == 0 && KS >= LEAD, "the register-set rotation must repeat per chunk");
+#define READ_STEP(set_, tap_, ks_) conv_read_step<NSET, MB, NB, ROWB, BS_BYTES, ALLTAPS, set_, tap_, ks_>(fa, fb, a_lane, wm * MB * CB_PW + l31, b_par0, hh)
+        STAMP(3 + nti * 4)
+        if (ALLTAPS || nti == 0) { READ_STEP(0, 0, 0); if constexpr (LEAD > 1) READ_STEP(1 % NSET, 0, 1); }   // later N tiles: issued by the previous N tile's last steps
         for (int q = 0; q < Q; ++q) {
             const bool last_chunk = (q + 1 >= Q);
+            const bool more_segs = !last_chunk || has_next_nt;             // another (N tile, chunk) segment follows in the stream
+            const int qn = last_chunk ? 0 : q + 1, ntn = last_chunk ? nt + 1 : nt;
+            const bool carry = !ALLTAPS && (Q == 1) && has_next_nt;        // same patch next: the pipeline runs on into the next N tile
             orn_sfor<0, 9>([&](auto tap_c) __attribute__((always_inline)) {
                 constexpr int tap = decltype(tap_c)::value;
                 constexpr int buf = ALLTAPS ? tap : tap % 3;
                 orn_sfor<0, KS>([&](auto ks_c) __attribute__((always_inline)) {
                     constexpr int ks = decltype(ks_c)::value;
-                    constexpr int cur = ks & 1;
-                    constexpr bool more = (ks + 1 < KS) || (tap < 8);
-                    if constexpr (ks + 1 < KS) READ_STEP(cur ^ 1, tap, ks + 1);
-                    else if constexpr (tap < 8) READ_STEP(0, tap + 1, 0);
-                    conv_wait_set<MB, NB, cur, (more ? NR : 0)>(fa, fb);
+                    constexpr int g = tap * KS + ks, cur = g % NSET, nxt = (g + LEAD) % NSET;
+                    constexpr int g2 = g + LEAD;                           // the step whose reads are issued now
+                    if constexpr (g2 < NSTEP) {
+                        READ_STEP(nxt, g2 / KS, g2 % KS);
+                        conv_wait_set<NSET, MB, NB, cur, LEAD * NR>(fa, fb);
+                    } else if (carry) {                                    // first steps of the next N tile
+                        READ_STEP(nxt, 0, g2 - NSTEP);
+                        conv_wait_set<NSET, MB, NB, cur, LEAD * NR>(fa, fb);
+                    } else
+                        conv_wait_set<NSET, MB, NB, cur, (NSTEP - 1 - g) * NR>(fa, fb);
 #pragma unroll
                     for (int i = 0; i < MB; ++i)
 #pragma unroll
                         for (int j = 0; j < NB; ++j) acc[i][j] = MFMA_H16(fb[cur][j], fa[cur][i], acc[i][j]);
                 });
-                if (!ALLTAPS && ((tap < 8) || !last_chunk)) {
-                    WAIT_VM(0);                     // this wave's pieces of every tile in flight (tile tt+2) have landed
+                STAMP_TAP(nti * Q + q, tap)
+                if (!ALLTAPS && ((tap < 8) || more_segs)) {
+                    // stream per wave: .. DMA (tap 8) [epilogue: NST stores] | tap 0: wait for that DMA only, DMA | tap 1: wait all ..
+                    if constexpr (EPI_IS_FWD(EPI) && tap == 0) {
+                        if (pending) WAIT_VMC(NST); else WAIT_VM(0);
+                        pending = false;
+                    } else {
+                        STAMP_BAR(nti * Q + q, tap, 0)
+                        WAIT_VM(0);                 // this wave's pieces of every tile in flight (tile tt+2) have landed
+                        STAMP_BAR(nti * Q + q, tap, 1)
+                    }
                     if (!(PDBG(p) & 8)) BARRIER();
-                    if constexpr (tap == 8) {       // next chunk: everyone is done with the old chunk's patch
-                        if (!(PDBG(p) & 2)) DMA_PATCH(q + 1)
-                        WAIT_VM(0);
-                        BARRIER();
+                    STAMP_BAR(nti * Q + q, tap, 2)
+                    if constexpr (tap == 8) {
+                        if (Q > 1) {                // next chunk: everyone is done with the old chunk's patch
+                            if (!(PDBG(p) & 2)) DMA_PATCH(qn)
+                            WAIT_VM(0);
+                            BARRIER();
+                        }
                     }
                     if (!(PDBG(p) & 1)) {           // tile tt + 3 into the buffer of tile tt (free now)
                         if constexpr (tap < 6) DMA_B(buf, nt, q, tap + 3)
-                        else if (!last_chunk) DMA_B(buf, nt, q + 1, tap - 6)
+                        else if (more_segs) DMA_B(buf, ntn, qn, tap - 6)
                     }
-                    if constexpr (tap == 8) READ_STEP(0, 0, 0);
+                    if constexpr (tap == 8) {
+                        if (Q > 1) { READ_STEP(0, 0, 0); if constexpr (LEAD > 1) READ_STEP(1 % NSET, 0, 1); }
+                    }
                 }
             });
         }
+        // a carried-over prefetch lands before the epilogue's code runs (the compiler may move those registers there)
+        if (!ALLTAPS && (Q == 1) && has_next_nt) { conv_wait_set<NSET, MB, NB, 0, (LEAD - 1) * NR>(fa, fb); if constexpr (LEAD > 1) conv_wait_set<NSET, MB, NB, 1 % NSET, 0>(fa, fb); }
 #undef READ_STEP
+        STAMP(4 + nti * 4)
 
         // ---- epilogue --------------------------------------------------------------------------
         // Lane (pixel l31, half hh) holds channels 8g + 4hh + e (g = reg>>2, e = reg&3) of each 32-ch block.
@@ -385,17 +454,15 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
                         const int ij = conv_div(c8, p.mCn), n = c8 - ij * p.Cn;
                         const int si = conv_div(ij, p.mS), sj = ij - si * p.s;
                         const int Ws = W * p.s, oh = gh * p.s + si, ow = gw * p.s + sj;
-                        constexpr int DI_ = 0;
-                        const int di = EPI_IS_FWD(EPI) ? ((i * NB + j) * 2 + k / 2) : DI_;
-                        dz[di] = u32x4{za0, za1, zb0, zb1};
-                        dzo[di] = (oh * Ws + ow) * p.Cn + n;                      // < 2^31: checked by the launcher
-                        dok[di] = ok;
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{za0, za1, zb0, zb1}, z_rsrc,
+                                                               ok ? ((oh * Ws + ow) * p.Cn + n) * 2 : (int)0x80000000, 0, 0);   // < 2^31 bytes: launcher
                         if (APAD) {
                             unsigned aa0 = pack_h16x2(orn_silu(va[0]), orn_silu(va[1])), aa1 = pack_h16x2(orn_silu(va[2]), orn_silu(va[3]));
                             unsigned ab0 = pack_h16x2(orn_silu(vb[0]), orn_silu(vb[1])), ab1 = pack_h16x2(orn_silu(vb[2]), orn_silu(vb[3]));
                             swap_halves(aa0, ab0); swap_halves(aa1, ab1);
-                            da[di] = u32x4{aa0, aa1, ab0, ab1};
-                            dao[di] = ((oh + 1) * (Ws + 2) + (ow + 1)) * p.Cn + n;
+                            // the activation copy leaves right away (the next vmcnt wait is a whole tap of the next N tile away)
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{aa0, aa1, ab0, ab1}, a_rsrc,
+                                                                   ok ? (((oh + 1) * (Ws + 2) + (ow + 1)) * p.Cn + n) * 2 : (int)0x80000000, 0, 0);
                         }
                     } else {
                         float v[8];
@@ -426,11 +493,13 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
             }
         }
         if (EPI_IS_FWD(EPI)) pending = true;
+        STAMP(5 + nti * 4)
     }
-    if (EPI_IS_FWD(EPI) && pending) FLUSH_DEFERRED()
+    STAMP(2 + nt_cnt * 4)
+    STAMP_RT(1)
+    STAMP_FLUSH()
 }
 
-#undef FLUSH_DEFERRED
 #undef DMA16
 #undef DMA_B
 #undef DMA_PATCH
@@ -443,7 +512,10 @@ static int launch_conv_cfg(const ConvBP &p, int n_tiles_total, hipStream_t st)
     constexpr int BN = WAVES_N * NB * 32;
     constexpr int NT = WAVES_M * WAVES_N * 64;
     constexpr size_t LDS_IMG = (size_t)(CB_PH * CB_PW * CK * 2 + 1023) / 1024 * 1024 + (ALLTAPS ? 9 : 3) * (size_t)BN * CK * 2;
-    const size_t smem = LDS_IMG + (EPI_IS_FWD(EPI) ? orn_align((size_t)p.Nout * 4) : 0);   // + bias copy
+    size_t smem = LDS_IMG + (EPI_IS_FWD(EPI) ? orn_align((size_t)p.Nout * 4) : 0);   // + bias copy
+#ifdef ORN_CONV_STAMP
+    smem += 1024;
+#endif
     auto kern = k_conv_nhwc_bf16<WAVES_M, WAVES_N, MB, NB, EPI, CK, ALLTAPS>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -485,10 +557,15 @@ int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p
     ORN_REQUIRE(Cin % CB_CK == 0 && O % 128 == 0 && O % (s * s) == 0, "conv_bf16_fwd: unsupported Cin=%d O=%d s=%d", Cin, O, s);
     ConvBP p = {};
     p.dbg = g_conv_dbg;
+#ifdef ORN_CONV_STAMP
+    p.stamps = g_conv_stamps;
+#endif
     p.xpad = xpad; p.w = wb; p.bias = bias_p; p.H = H; p.W = W; p.Cin = Cin; p.Nout = O;
     p.tiles_w = orn_cdiv(W, CB_TW); p.tiles_h = orn_cdiv(H, CB_TH);
     p.z = z; p.apad = apad; p.s = s; p.Cn = O / (s * s);
-    ORN_REQUIRE(O <= 2048 && s < 65536 && (long)(H * s + 2) * (W * s + 2) * p.Cn < 2147483647L, "conv_bf16_fwd: sizes exceed the 32-bit index math");
+    ORN_REQUIRE(O <= 2048 && s < 65536 && (long)(H * s + 2) * (W * s + 2) * p.Cn < 1073741824L, "conv_bf16_fwd: sizes exceed the 32-bit index math");
+    p.z_bytes = (unsigned)((size_t)(H * s) * (W * s) * p.Cn * 2);
+    p.apad_bytes = apad ? (unsigned)((size_t)(H * s + 2) * (W * s + 2) * p.Cn * 2) : 0;
     p.mCn = conv_magic(p.Cn); p.mS = conv_magic(s);
     const int nt_total = O / 128;
     // One work-group per CU (LDS): keep a pixel tile's N tiles together (patch staged once) unless cutting them
@@ -543,6 +620,9 @@ int orn_launch_conv_bf16_dgrad(const h16 *dypad, const h16 *wd, int H, int W, in
     ORN_REQUIRE(O % CB_CK == 0 && C == 96, "conv_bf16_dgrad: unsupported O=%d C=%d", O, C);
     ConvBP p = {};
     p.dbg = g_conv_dbg;
+#ifdef ORN_CONV_STAMP
+    p.stamps = g_conv_stamps;
+#endif
     p.xpad = dypad; p.w = wd; p.bias = nullptr; p.H = H; p.W = W; p.Cin = O; p.Nout = C;
     p.tiles_w = orn_cdiv(W, CB_TW); p.tiles_h = orn_cdiv(H, CB_TH);
     p.n_tiles_per_wg = 1;
@@ -1511,6 +1591,9 @@ extern "C" int orn_dgrad_nhwc_bf16(const void *dypad, const void *wd, int H, int
 }
 
 extern "C" void orn_debug_set(int flags) { set_debug(flags); }   // timing experiments only (tools/probes)
+#ifdef ORN_CONV_STAMP
+extern "C" void orn_debug_set_stamps(void *buf) { g_conv_stamps = (unsigned long long *)buf; }
+#endif
 #endif  // !ORN_FP16
 
 }  // namespace HNS
