@@ -1,17 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- training frames/sec of the Online-RepNeRV hot path on MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched under
-torch.distributed.run (one rank per GPU, RCCL).  A "step" is one optimiser step on one frame
-(main_train.py:229-254: stem, 5x{online ERB merge, conv3x3+PixelShuffle+SiLU}, head, Fusion6 loss +
-PSNR, backward, Adam) of BASELINE config 2 (Bunny-shaped 132x1280x720 synthetic video, ERB,
-fc_hw_dim 9_16_26, strides 5 2 2 2 2) with the video already resident in HBM.  Independent
-per-video fits shard one per rank with no data-path collective ("scaling": "weak"); RCCL is used only
-for the barrier / max-over-ranks reduction.  Rank 0 prints ONE JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  For N > 1 it either runs under
+torch.distributed.run (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or, started
+without WORLD_SIZE, launches its own N ranks (fresh child processes, one per device, spawned before this process touches
+the GPU) and relays rank 0's line.  A "step" is one optimiser step on one frame (main_train.py:229-254: stem,
+5 x {online ERB merge, conv3x3+PixelShuffle+SiLU}, head, Fusion6 loss + PSNR, backward, Adam) of BASELINE config 2
+(Bunny-shaped 132x1280x720 synthetic video, ERB, fc_hw_dim 9_16_26, strides 5 2 2 2 2) with the video already
+resident in HBM.  Independent per-video fits shard one per rank with no data-path collective ("scaling": "weak"); RCCL
+carries only the barrier, the max-over-ranks time and the per-rank rates.  Rank 0 prints ONE JSON line.
+
+The headline `value` is the engine's 16-bit mode (--precision fp16: IEEE-half activations and MFMA operands, fp32
+accumulate, fp32 master weights / merge / loss / Adam, dynamic loss scale).  The reference trains in fp32, so the same
+line carries the fp32 engine's own record under "fp32" (same step, same video, exact-fp32 MFMA), measured in this run.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -19,35 +26,52 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 CFG = dict(embed='1.25_40', stem_dim_num='512_1', fc_hw_dim='9_16_26', expansion=1, reduction=2, lower_width=96,
            strides=[5, 2, 2, 2, 2], frames=132, lr=5e-4, epochs=300, warmup=60, beta=0.5, loss='Fusion6')
-FLOP_STEP = 605.65e9          # algorithmic FLOPs per trained 720p frame, 3x fwd
+CONFIGS = {
+    # BASELINE config 2 (the metric's config) and config 3's geometry (optional line, --config 1080p)
+    '720p': dict(fc_hw_dim='9_16_26', strides=[5, 2, 2, 2, 2], hw=(720, 1280), flop_step=605.65e9,
+                 name='configs[1]: Bunny-shaped 132x3x720x1280 synthetic video, branch_type=ERB, fc_hw_dim 9_16_26, strides 5 2 2 2 2'),
+    '1080p': dict(fc_hw_dim='9_16_48', strides=[5, 3, 2, 2, 2], hw=(1080, 1920), flop_step=1366.56e9,
+                  name='configs[2] geometry: 132x3x1080x1920 synthetic video, branch_type=ERB, fc_hw_dim 9_16_48, strides 5 3 2 2 2'),
+}
+PEAK = {'fp32': 157.3, 'bf16': 2500.0, 'fp16': 2500.0}       # TFLOP/s: fp32 MFMA / dense 16-bit MFMA (MI355X_MICROARCH.md)
+# kernel symbols as rocprofv3 prints them (template arguments: waves M x N, wave tile M x N, epilogue, K chunk, all-taps)
+SYM = {'fwd_last': 'k_conv_nhwc_bf16<4, 2, 2, 2, 3, 96, false>', 'fwd': 'k_conv_nhwc_bf16<4, 2, 2, 2, 0, 96, false>',
+       'fwd_narrow': 'k_conv_nhwc_bf16<4, 2, 2, 2, 0, 32, true>', 'dgrad': 'k_conv_nhwc_bf16<8, 1, 1, 3, 1, 96, false>',
+       'dgrad_split': 'k_conv_nhwc_bf16<8, 1, 1, 3, 2, 96, false> + k_dgrad_finish',
+       'dgrad_narrow': 'k_conv_nhwc_bf16<8, 1, 1, 1, 2, 96, true>', 'wgrad': 'k_wgrad_nhwc_bf16_all',
+       'wgrad_reduce': 'k_wgrad_bf16_reduce_all'}
 
 
-def layer_geo():
-    from orn_amd import model  # noqa: F401
-    C, H, W = 26, 9, 16
+def layer_geo(cfg):
+    fc_h, fc_w, C = (int(x) for x in cfg['fc_hw_dim'].split('_'))
+    H, W = fc_h, fc_w
     out = []
-    for i, s in enumerate(CFG['strides']):
+    for i, s in enumerate(cfg['strides']):
         new = int(C * CFG['expansion']) if i == 0 else max(C // CFG['reduction'], CFG['lower_width'])
-        out.append(dict(C=C, O=new * s * s, s=s, H=H, W=W))
+        out.append(dict(C=C, O=new * s * s, s=s, H=H, W=W, flops=2.0 * C * 9 * new * s * s * H * W))
         C, H, W = new, H * s, W * s
     return out
 
 
-def make_engine(seed, precision, branch_type='ERB', noise=0.1, fc_hw_dim=None, strides=None, hw=(720, 1280), frames=None):
+def make_engine(seed, precision, cfg=None, branch_type='ERB', noise=0.1, fc_hw_dim=None, strides=None, hw=None, frames=None,
+                kind='waves', init_seed=1):
+    """Engine + resident synthetic video.  cfg: an entry of CONFIGS (default 720p), or the geometry given piecewise."""
+    import torch
+    cfg = dict(cfg or CONFIGS['720p'])
+    if fc_hw_dim:
+        cfg.update(fc_hw_dim=fc_hw_dim, strides=strides, hw=hw)
     from orn_amd import engine, model, ops
     from orn_amd.data import synthetic_video
-    torch.manual_seed(1)                                    # main_train.py:162
-    gen = model.Generator(embed_length=80, stem_dim_num=CFG['stem_dim_num'], fc_hw_dim=fc_hw_dim or CFG['fc_hw_dim'],
+    torch.manual_seed(init_seed)                            # main_train.py:162 (seed 1)
+    gen = model.Generator(embed_length=80, stem_dim_num=CFG['stem_dim_num'], fc_hw_dim=cfg['fc_hw_dim'],
                           expansion=CFG['expansion'], num_blocks=1, norm='none', act='swish', bias=True,
-                          reduction=CFG['reduction'], conv_type='conv', stride_list=strides or CFG['strides'], sin_res=True,
+                          reduction=CFG['reduction'], conv_type='conv', stride_list=cfg['strides'], sin_res=True,
                           lower_width=CFG['lower_width'], sigmoid=False, deploy=False, branch_type=branch_type)
     eng = engine.TrainEngine(gen, loss_type=CFG['loss'], beta=CFG['beta'], precision=precision)
     n = frames or CFG['frames']
-    frames = synthetic_video(n, hw[0], hw[1], seed=seed, device=eng.device, noise=noise)
+    frames = synthetic_video(n, cfg['hw'][0], cfg['hw'][1], seed=seed, device=eng.device, noise=noise, kind=kind)
     pos = torch.tensor([float(k) / n for k in range(n)], dtype=torch.float32)
     embeds = ops.pe_forward(pos.to(eng.device), 1.25, 40)
     eng.set_video(frames, embeds)
@@ -56,6 +80,7 @@ def make_engine(seed, precision, branch_type='ERB', noise=0.1, fc_hw_dim=None, s
 
 def schedule(n_steps, start_step=0):
     """Shuffled-epoch frame order + the reference LR schedule (utils.py:240-259)."""
+    import torch
     from orn_amd import utils
 
     class A:
@@ -73,51 +98,88 @@ def schedule(n_steps, start_step=0):
     return out
 
 
-def conv_roofline(eng, precision, iters=20):
-    """Dominant kernel = the implicit-GEMM 3x3 conv forward.  fp32: k_conv3x3_f32<EPI_PS_SILU>, one launch per layer
-    (L0..L4); 16-bit: k_conv_nhwc_bf16<4,2,2,2,EPI_B_FWD_LAST>, the last block's forward (one launch per step,
-    152.9 GF at 720p); the earlier fast layers run the <..,EPI_B_FWD> instantiation and are listed in per_layer.  Durations are measured LIVE inside real training steps: the engine
-    runs `iters` eager steps with HIP events bracketing every layer's forward conv launch on the launch stream
-    (orn_engine_profile_step), so clocks, caches and operands are those of the step -- the same launches rocprofv3
-    averages for the symbol.  Returns (algorithmic flops per launch, avg launch duration [s], per-layer list)."""
-    geo = layer_geo()
-    ff = 0
-    if precision in ('bf16', 'fp16'):
-        # the engine's rule (orn_engine.hip first_fast_layer): trailing layers with C == 96 and O % 128 == 0, plus one
-        # narrower layer below them run zero-padded to 96 channels
-        ff = len(geo)
-        while ff > 0 and geo[ff - 1]['C'] == 96 and geo[ff - 1]['O'] % 128 == 0:
-            ff -= 1
-        if 0 < ff < len(geo) and geo[ff - 1]['C'] < 96 and geo[ff - 1]['O'] % 128 == 0:
-            ff -= 1
+def first_fast_layer(geo, precision):
+    """The engine's rule (orn_engine.hip first_fast_layer): trailing layers with C == 96 on the 16-bit kernels, plus one
+    narrower layer below them zero-padded to 96 channels."""
+    if precision == 'fp32':
+        return len(geo)
+    ff = len(geo)
+    while ff > 0 and geo[ff - 1]['C'] == 96 and geo[ff - 1]['O'] % 128 == 0:
+        ff -= 1
+    if 0 < ff < len(geo) and geo[ff - 1]['C'] < 96 and geo[ff - 1]['O'] % 128 == 0:
+        ff -= 1
+    return ff
+
+
+def conv_kernels(eng, precision, cfg, iters=20):
+    """Durations of the conv launches measured LIVE inside real training steps: `iters` eager steps with HIP events around
+    every forward conv, every dgrad launch, the batched wgrad launch and its reduction, on the launch stream
+    (orn_engine_profile_step) -- the same launches rocprofv3 averages per symbol.  Returns the per-symbol table
+    [{kernel, launches_per_step, us_per_step, gflop_per_step, tflops, frac}] (algorithmic FLOPs: real channels only)."""
+    geo = layer_geo(cfg)
+    nl = len(geo)
+    ff = first_fast_layer(geo, precision)
     eng.set_schedule(schedule(iters + 2))
-    acc = [0.0] * len(geo)
+    acc = None
     for k in range(iters + 2):
         ms = eng.profile_step()
         if k >= 2:
-            acc = [a + m for a, m in zip(acc, ms)]
-    per_layer, tot_t, tot_f, n = [], 0.0, 0.0, 0
-    for li, L in enumerate(geo):
-        if li < ff:
-            continue
-        dt = acc[li] / iters / 1e3
-        fl = 2.0 * L['C'] * 9 * L['O'] * L['H'] * L['W']          # algorithmic: the real input channels only
-        per_layer.append(dict(layer=li, ms=dt * 1e3, tflops=fl / dt / 1e12))
-        tot_t += dt
-        tot_f += fl
-        n += 1
-    if precision in ('bf16', 'fp16'):
-        # the last block's forward is its own kernel symbol (<..,EPI_B_FWD_LAST>: no activation copy), one launch per
-        # step and 76 % of the forward FLOPs: that launch is the roofline kernel
-        last = per_layer[-1]
-        L = geo[-1]
-        return 2.0 * L['C'] * 9 * L['O'] * L['H'] * L['W'], last['ms'] / 1e3, per_layer
-    return tot_f / n, tot_t / n, per_layer
+            flat = ms['fwd'] + ms['dgrad'] + [ms['wgrad'], ms['wgrad_reduce']]
+            acc = flat if acc is None else [a + b for a, b in zip(acc, flat)]
+    us = [a / iters * 1e3 for a in acc]
+    fwd, dgr, wg, wr = us[:nl], us[nl:2 * nl], us[2 * nl], us[2 * nl + 1]
+    rows = {}
+
+    def add(key, t_us, fl):
+        r = rows.setdefault(key, dict(kernel=key, launches_per_step=0, us_per_step=0.0, gflop_per_step=0.0))
+        r['launches_per_step'] += 1
+        r['us_per_step'] += t_us
+        r['gflop_per_step'] += fl / 1e9
+
+    if precision == 'fp32':
+        for i, L in enumerate(geo):
+            add('k_conv3x3_f32<EPI_PS_SILU> (forward, L0..L%d)' % (nl - 1), fwd[i], L['flops'])
+            add('fp32 backward call per layer (dgrad + wgrad + dbias kernels)', dgr[i], 2 * L['flops'])
+    else:
+        ns = 'orn_f16::' if precision == 'fp16' else 'orn_bf16::'
+        for i in range(ff, nl):
+            L = geo[i]
+            narrow = L['C'] <= 32
+            add(ns + (SYM['fwd_last'] if i == nl - 1 else (SYM['fwd_narrow'] if narrow else SYM['fwd'])), fwd[i], L['flops'])
+            small = ((L['W'] + 31) // 32) * ((L['H'] + 7) // 8) < 128 and L['O'] // 96 > 1     # orn_launch_conv_bf16_dgrad
+            if i == ff:
+                add(ns + (SYM['dgrad_narrow'] if (small and narrow) else SYM['dgrad_split']) + ' (fp32 hand-off)', dgr[i], L['flops'])
+            else:
+                add(ns + (SYM['dgrad_split'] if small else SYM['dgrad']), dgr[i], L['flops'])
+        add(ns + SYM['wgrad'] + ' (all 16-bit layers in one launch)', wg, sum(geo[i]['flops'] for i in range(ff, nl)))
+        add(ns + SYM['wgrad_reduce'] + ' (split-K slab reduction: HBM-bound, no MFMA work)', wr, 0.0)
+    out = []
+    for r in rows.values():
+        r['tflops'] = r['gflop_per_step'] / r['us_per_step'] * 1e3 if r['us_per_step'] > 0 else 0.0
+        r['frac'] = r['tflops'] / PEAK[precision]
+        out.append(r)
+    out.sort(key=lambda r: -r['us_per_step'])
+    return out
+
+
+def traffic_for(kernel):
+    """HBM bytes per launch from the committed PMC pass (profiles/conv_traffic.json, collected as MI355X_MICROARCH.md
+    prescribes: FETCH_SIZE and WRITE_SIZE in separate --pmc runs, reads doubled for wide coalesced loads).  The file names
+    the kernel symbol it was measured on; a symbol that is not the one priced here is REFUSED (None)."""
+    path = os.path.join(ROOT, 'profiles', 'conv_traffic.json')
+    if not os.path.exists(path):
+        return None
+    want = kernel.split('::', 1)[-1].split(' (')[0].split(' + ')[0]           # template name without namespace / notes
+    for rec in json.load(open(path)).get('kernels', []):
+        if rec.get('symbol', '').split('::', 1)[-1].startswith(want):
+            return rec.get('traffic_bytes_per_launch')
+    return None
 
 
 def cpu_baseline(steps=8):
     """The CPU oracle ("port": same ATen CPU ops as the reference's CPU path) timed on this host,
     bounded sample: 1 warm-up + `steps` ERB training steps at 720p with Fusion6."""
+    import torch
     from oracle import cpu_ref
     # the 1-GPU box's CPU share is 16 cores; oneDNN with all 256 hardware threads is pathologically slow
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
@@ -138,84 +200,193 @@ def cpu_baseline(steps=8):
                        f'{torch.get_num_threads()} threads')
 
 
+class StubEngine:
+    """--cpu-stub (tests of the launcher / reduction path on machines without a GPU): a step is a short sleep."""
+
+    def set_schedule(self, s):
+        self.n = len(s)
+
+    def run(self, n, graph=True):
+        time.sleep(0.002 * n)
+
+    def stats(self, n):
+        import torch
+        return torch.zeros(n, 8)
+
+
+def timed_leg(eng, steps, warmup, graph, dist, device_sync):
+    """W untimed + K timed steps, barrier + synchronize on both sides, MAX over ranks.  Returns (dt_max, dt_own, stats)."""
+    import torch
+    eng.set_schedule(schedule(warmup + steps))
+    eng.run(warmup, graph=graph)
+    device_sync()
+    if dist:
+        dist.barrier()
+    device_sync()
+    t0 = time.perf_counter()
+    eng.run(steps, graph=graph)
+    device_sync()
+    own = time.perf_counter() - t0
+    if dist:
+        dist.barrier()
+    device_sync()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda' if torch.cuda.is_available() and dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, own, eng.stats(warmup + steps)
+
+
+def worker(args):
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    stub = args.cpu_stub
+    if os.environ.get('ORN_BENCH_FAIL_RANK') == str(rank):          # tests: a rank that dies before the rendezvous
+        raise SystemExit(3)
+    if not stub:
+        torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(args.backend, rank=rank, world_size=world)     # "nccl" = RCCL over xGMI
+    device_sync = (lambda: None) if stub else torch.cuda.synchronize
+    cfg = CONFIGS[args.config]
+    graph = not args.no_graph
+
+    eng = StubEngine() if stub else make_engine(seed=1234 + rank, precision=args.precision, cfg=cfg)   # one independent video per rank
+    dt, own, stats = timed_leg(eng, args.steps, args.warmup, graph, dist, device_sync)
+    psnr_last = float(stats[args.warmup:, 4].mean())
+    ok = bool(torch.isfinite(stats[:, 0]).all())
+    per_rank = [args.steps / own]
+    if dist:
+        lst = [None] * world
+        dist.all_gather_object(lst, args.steps / own)
+        per_rank = [float(x) for x in lst]
+
+    if rank == 0:
+        out = {
+            'metric': 'training frames/sec, Bunny 720p ERB', 'value': world * args.steps / dt, 'unit': 'frames/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': {'fp32': 'f32', 'bf16': 'bf16', 'fp16': 'f16'}[args.precision], 'data': 'synthetic',
+            'config': {'workload': cfg['name'] + ', stem 512_1, lower_width 96, Fusion6, Adam(0.5,0.999), b=1; one independent video per GPU',
+                       'precision': args.precision, 'hip_graph': graph,
+                       'timed_region': 'optimiser steps incl. loss, backward, Adam, per-step PSNR; MS-SSIM logging excluded, checkpoint I/O excluded',
+                       'train_psnr_mean_timed_steps': psnr_last, 'finite': ok,
+                       'whole_step_tflops': world * args.steps / dt * cfg['flop_step'] / 1e12},
+            'rccl_ranks': (dist.get_world_size() if dist else 1), 'per_rank_frames_per_s': per_rank,
+        }
+        if args.config != '720p':
+            out['metric'] = f'training frames/sec, {args.config} ERB (not the BASELINE metric config)'
+        if not stub:
+            sc = eng.scale_state()
+            out['config']['loss_scale'] = {'scale': sc['scale'], 'steps_skipped': sc['skipped'], 'halvings': sc['backoffs']}
+            kern = conv_kernels(eng, args.precision, cfg)
+            dom = next(k for k in kern if k['gflop_per_step'] > 0)   # dominant by time (among the kernels that do MFMA work)
+            step_us = dt / args.steps * 1e6
+            out['roofline'] = {
+                'bound': 'mfma', 'achieved': dom['tflops'], 'peak': PEAK[args.precision], 'unit': 'TFLOP/s', 'frac': dom['frac'],
+                'traffic': traffic_for(dom['kernel']), 'kernel': dom['kernel'] + f" ({dom['launches_per_step']} launches/step; dominant by time)",
+                'flops_per_launch': dom['gflop_per_step'] * 1e9 / dom['launches_per_step'],
+                'avg_launch_ms': dom['us_per_step'] / dom['launches_per_step'] / 1e3,
+                'kernels': kern,
+                'whole_step_frac': (cfg['flop_step'] / (step_us * 1e-6) / 1e12) / PEAK[args.precision],
+                'conv_us_per_step': sum(k['us_per_step'] for k in kern), 'step_us': step_us,
+            }
+            del eng
+            torch.cuda.empty_cache()
+            if not args.no_fp32 and args.precision != 'fp32' and world == 1:
+                # the reference's own arithmetic: the same step on the exact-fp32 engine, measured in this run
+                e32 = make_engine(seed=1234 + rank, precision='fp32', cfg=cfg)
+                s32 = min(args.steps, args.fp32_steps)
+                w32 = min(args.warmup, 12)
+                dt32, _, st32 = timed_leg(e32, s32, w32, graph, None, device_sync)
+                k32 = conv_kernels(e32, 'fp32', cfg, iters=6)
+                d32 = k32[0]
+                out['fp32'] = {
+                    'value': s32 / dt32, 'unit': 'frames/s', 'steps': s32, 'warmup': w32, 'ms_per_step': dt32 / s32 * 1e3, 'dtype': 'f32',
+                    'finite': bool(torch.isfinite(st32[:, 0]).all()), 'train_psnr_mean_timed_steps': float(st32[w32:, 4].mean()),
+                    'whole_step_tflops': s32 / dt32 * cfg['flop_step'] / 1e12,
+                    'roofline': {'bound': 'mfma', 'achieved': d32['tflops'], 'peak': PEAK['fp32'], 'unit': 'TFLOP/s', 'frac': d32['frac'],
+                                 'kernel': d32['kernel'], 'kernels': k32,
+                                 'whole_step_frac': (s32 / dt32 * cfg['flop_step'] / 1e12) / PEAK['fp32']},
+                }
+                del e32
+                torch.cuda.empty_cache()
+            if not args.no_cpu_baseline and world == 1 and args.config == '720p':
+                out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def launch(args):
+    """`--gpus N` without an outer launcher: N fresh child processes, one rank per device.  This process has not touched the
+    GPU (no torch.cuda call before this point) and never execs; a failing rank makes the whole run fail."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   ORN_BENCH_CHILD='1')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=(subprocess.PIPE if r == 0 else subprocess.DEVNULL), text=True))
+    # rank 0's line is read by a thread; the ranks are polled so that one dying rank ends the run (its peers would wait in
+    # the rendezvous or a barrier forever): the children this process started are then terminated by PID
+    import threading
+    buf = []
+    th = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    th.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = r
+        time.sleep(0.05)
+    if failed is None:
+        failed = next((r for r, p in enumerate(procs) if p.returncode != 0), None)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        sys.stderr.write(f'bench.py: rank {failed} failed (exit codes {[p.returncode for p in procs]})\n')
+        raise SystemExit(1)
+    th.join(timeout=10)
+    sys.stdout.write(buf[0] if buf else '')
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=264)
     ap.add_argument('--warmup', type=int, default=66)
     ap.add_argument('--precision', default=os.environ.get('ORN_PRECISION', 'fp16'), choices=['fp32', 'bf16', 'fp16'])
+    ap.add_argument('--config', default='720p', choices=sorted(CONFIGS))
+    ap.add_argument('--fp32-steps', type=int, default=66, help='timed steps of the fp32 record (at most --steps)')
+    ap.add_argument('--no-fp32', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'])
+    ap.add_argument('--cpu-stub', action='store_true', help='no GPU: exercise launcher + reduction only (tests)')
     args = ap.parse_args()
-
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})')
-    torch.cuda.set_device(local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)     # RCCL over xGMI
-
-    eng = make_engine(seed=1234 + rank, precision=args.precision)        # one independent video per rank
-    sched = schedule(args.warmup + args.steps)
-    eng.set_schedule(sched)
-    graph = not args.no_graph
-    eng.run(args.warmup, graph=graph)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    eng.run(args.steps, graph=graph)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    stats = eng.stats(args.warmup + args.steps)
-    psnr_last = float(stats[args.warmup:, 4].mean())
-    ok = bool(torch.isfinite(stats[:, 0]).all())
-
-    if rank == 0:
-        fl, avg_dt, per_layer = conv_roofline(eng, args.precision)
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'conv_fwd_traffic.json')
-        if args.precision != 'fp32' and os.path.exists(tpath):       # PMC pass collected separately (see the file's "method")
-            traffic = json.load(open(tpath))['layers'][-1]['traffic_bytes']     # the last block's launch (the roofline kernel)
-        peak = 157.3 if args.precision == 'fp32' else 2500.0      # fp32 MFMA / dense 16-bit MFMA (bf16 and f16 share the rate)
-        achieved = fl / avg_dt / 1e12
-        out = {
-            'metric': 'training frames/sec, Bunny 720p ERB', 'value': world * args.steps / dt, 'unit': 'frames/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'fp32': 'f32', 'bf16': 'bf16', 'fp16': 'f16'}[args.precision], 'data': 'synthetic',
-            'config': {'workload': 'configs[1]: Bunny-shaped 132x3x720x1280 synthetic video, branch_type=ERB, fc_hw_dim 9_16_26, '
-                                   'strides 5 2 2 2 2, stem 512_1, lower_width 96, Fusion6, Adam(0.5,0.999), b=1; '
-                                   'one independent video per GPU', 'precision': args.precision, 'hip_graph': graph,
-                       'train_psnr_mean_timed_steps': psnr_last, 'finite': ok,
-                       'whole_step_tflops': world * args.steps / dt * FLOP_STEP / 1e12},
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'traffic': traffic,
-                         'kernel': ('k_conv3x3_f32<EPI_PS_SILU> (5 launches/step, L0..L4)' if args.precision == 'fp32'
-                                    else f'orn_{"bf16" if args.precision == "bf16" else "f16"}::k_conv_nhwc_bf16<4,2,2,2,EPI_B_FWD_LAST> '
-                                         f'(1 launch/step: forward conv of the last block, L{per_layer[-1]["layer"]}; per_layer lists the '
-                                         f'<..,EPI_B_FWD> launches of L{per_layer[0]["layer"]}..L{per_layer[-2]["layer"]} too)'),
-                         'flops_per_launch': fl, 'avg_launch_ms': avg_dt * 1e3, 'per_layer': per_layer},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out), flush=True)
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return launch(args)
+    worker(args)
 
 
 if __name__ == '__main__':

@@ -13,7 +13,7 @@ OBJ = os.path.join(HERE, 'build' + ('_' + TAG if TAG else ''))
 LIB = os.path.join(HERE, 'liborn' + ('_' + TAG if TAG else '') + '.so')
 EXTRA = os.environ.get('ORN_EXTRA_DEFS', '').split() if TAG else []
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function', '-fvisibility=hidden']
 
 
 def _sources():
@@ -23,6 +23,8 @@ def _sources():
 def _deps_mtime():
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
     hdrs.append(os.path.join(os.path.dirname(HERE), 'include', 'orn.h'))
+    hdrs.append(os.path.join(os.path.dirname(HERE), 'include', 'orn_debug.h'))
+    hdrs.append(os.path.join(CSRC, 'orn.map'))
     return max(os.path.getmtime(h) for h in hdrs)
 
 
@@ -60,7 +62,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 if warn and verbose:
                     print(warn, file=sys.stderr)
     if jobs or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
-        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        # dynamic symbol table = the C ABI of include/orn.h (+ orn_debug.h) only: kernel host stubs and internal launchers stay local
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,--version-script=' + os.path.join(CSRC, 'orn.map'), '-o', LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')

@@ -54,7 +54,10 @@ _SIGS = {
     'orn_dgrad_nhwc_bf16': (c_int, [P, P] + [c_int] * 4 + [P, P, c_int, P]),
     'orn_wgrad_nhwc_bf16_ws_bytes': (c_size_t, [c_int] * 3),
     'orn_wgrad_nhwc_bf16': (c_int, [P, P] + [c_int] * 5 + [P, P, P, P]),
-    'orn_debug_set': (None, [c_int]),
+    'orn_dgrad_nhwc_f16': (c_int, [P, P] + [c_int] * 4 + [P, P, c_int, P]),
+    'orn_wgrad_nhwc_f16': (c_int, [P, P] + [c_int] * 5 + [P, P, P, P]),
+    'orn_conv3x3_ps_silu_fwd_f16': (c_int, [P, P, P] + [c_int] * 5 + [P, P, P, c_size_t, P]),
+    'orn_conv3x3_ps_silu_bwd_f16': (c_int, [P, P, P, P] + [c_int] * 5 + [P, P, P, P, c_size_t, P]),
     'orn_head_fwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     'orn_head_bwd_ws_bytes': (c_size_t, [c_int] * 4),
     'orn_head_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
@@ -72,8 +75,12 @@ _SIGS = {
     'orn_engine_profile_step': (c_int, [P, P, P, P, P, P, c_int32, P, P]),
     'orn_engine_set_grad_mask': (c_int, [P, P]),
     'orn_engine_fused_kernel': (c_int, [P, c_int, POINTER(c_void_p), POINTER(c_void_p)]),
+    'orn_engine_scale_state': (c_int, [P, P]),
+    'orn_engine_set_grad_scale': (c_int, [P, c_float, c_float]),
 }
 EXPORTS = tuple(_SIGS.keys())
+# probe-only entry points (include/orn_debug.h): resolved if present, never required
+_DEBUG_SIGS = {'orn_debug_set': (None, [c_int]), 'orn_debug_set_stamps': (None, [c_void_p])}
 
 _lib = None
 
@@ -91,6 +98,11 @@ def lib():
             fn = getattr(L, name)          # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in _DEBUG_SIGS.items():
+            fn = getattr(L, name, None)
+            if fn is not None:
+                fn.restype = res
+                fn.argtypes = args
         _lib = L
     return _lib
 

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include "../../include/orn.h"
+#include "../../include/orn_debug.h"
 
 #define ORN_WAVE 64
 
@@ -123,6 +124,27 @@ __device__ __forceinline__ float orn_block_sum(float v, float *smem /* >= 16 flo
         for (int i = 0; i < nw; ++i) r += smem[i];
     }
     return r;
+}
+
+// Device-side dynamic loss scale + non-finite guard of the engine (one per engine, in its workspace; graph-safe: every
+// kernel reads it from memory, nothing is captured by value).  The 16-bit gradient tensors travel multiplied by `gs`
+// (fp16: 2^20 at the start; bf16 and fp32: 1).  Any kernel that meets a non-finite gradient on its way into the gradient
+// arena raises `flag`; Adam then leaves parameters and moments untouched (the step is skipped, as torch.cuda.amp.GradScaler
+// does) and the next schedule advance halves the scale.  After ORN_SCALE_GROWTH_INTERVAL clean steps it doubles again, up
+// to its initial value.
+struct OrnScaleState {
+    float gs, inv_gs;      // scale carried by the 16-bit gradient tensors, and its reciprocal
+    float gs_max;          // initial value: the scale never grows beyond it
+    int32_t flag;          // a non-finite gradient was seen since the last advance
+    int32_t skipped;       // optimiser steps skipped so far (Adam's bias corrections do not count them)
+    int32_t good;          // clean steps since the last change of scale
+    int32_t backoffs;      // times the scale was halved
+    int32_t pad;
+};
+#define ORN_SCALE_GROWTH_INTERVAL 2000
+__device__ __forceinline__ void orn_flag_nonfinite(OrnScaleState *sc, float v)
+{
+    if (sc && !(fabsf(v) <= 3.0e38f)) sc->flag = 1;      // NaN and +-inf; plain store: every writer stores the same value
 }
 
 // Device-side state of the step in flight (engine): schedule entry + derived Adam scalars.

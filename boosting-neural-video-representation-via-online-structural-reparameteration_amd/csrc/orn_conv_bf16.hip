@@ -819,8 +819,9 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p) { wgrad_b
 // dw/db = gscale * sum over blocks of the head backward's per-block partials [blocks][3C+3]: one work-group per column, lane
 // t sums rows t, t+256, .. in ascending order, fixed-order block tree after (deterministic).
 __device__ __forceinline__ void head_finish_body(const float *__restrict__ partial, int blocks, int C, float gscale, float *__restrict__ dw,
-                                                 float *__restrict__ db, int col, float *sred /* 256 floats of LDS */)
+                                                 float *__restrict__ db, int col, float *sred /* 256 floats of LDS */, OrnScaleState *sc = nullptr)
 {
+    if (sc) gscale = sc->inv_gs;
     const int n = 3 * C + 3, t = threadIdx.x;
     float acc = 0.f;
     for (int r = t; r < blocks; r += 256) acc += partial[(size_t)r * n + col];
@@ -832,6 +833,7 @@ __device__ __forceinline__ void head_finish_body(const float *__restrict__ parti
     }
     if (t == 0) {
         const float v = sred[0] * gscale;
+        orn_flag_nonfinite(sc, v);
         if (col < 3 * C) dw[col] = v;
         else db[col - 3 * C] = v;
     }
@@ -851,7 +853,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16_all(WgradBPAll a)
     if ((int)blockIdx.x >= a.start[a.n]) {
         extern __shared__ __attribute__((aligned(16))) unsigned char smem_hf[];
         head_finish_body(a.hf.partial, a.hf.blocks, a.hf.C, a.hf.gscale, a.hf.dw, a.hf.db, (int)blockIdx.x - a.start[a.n],
-                         reinterpret_cast<float *>(smem_hf));
+                         reinterpret_cast<float *>(smem_hf), a.hf.sc);
         return;
     }
     int k = 0;
@@ -863,8 +865,12 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16_all(WgradBPAll a)
 // dWf[o][c][i][j] = gscale * sum_s slabs[s][tap][o'(o)][c],  o' = (o % s2)*Cn + o / s2
 // Cr <= 96 real input channels (a narrower first fast layer runs zero-padded to 96): only those are written
 __device__ __forceinline__ void wgrad_reduce_body(const float *__restrict__ slabs, const float *__restrict__ bias_slabs, int S, int O, int Cn,
-                                                  int s2, int Cr, float gscale, float *__restrict__ dwf, float *__restrict__ dbf)
+                                                  int s2, int Cr, float gscale, float *__restrict__ dwf, float *__restrict__ dbf,
+                                                  OrnScaleState *sc = nullptr)
 {
+    // sc: the un-scaling factor comes from the device-side loss-scale state, and a non-finite result (an overflow of the
+    // 16-bit gradient tensors shows up in the bias gradient = plain sum of dy at the latest) raises its flag
+    if (sc) gscale = sc->inv_gs;
     const size_t n = (size_t)9 * O * 96;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < (size_t)O && dbf) {
@@ -872,6 +878,7 @@ __device__ __forceinline__ void wgrad_reduce_body(const float *__restrict__ slab
         for (int s = 0; s < S; ++s) b += bias_slabs[(size_t)s * O + idx];
         const int ij = (int)idx / Cn, nn = (int)idx - ij * Cn;
         dbf[nn * s2 + ij] = b * gscale;
+        orn_flag_nonfinite(sc, b * gscale);
     }
     if (idx >= n) return;
     const int c = (int)(idx % 96);
@@ -890,6 +897,7 @@ __device__ __forceinline__ void wgrad_reduce_body(const float *__restrict__ slab
     const int ij = op / Cn, nn = op - ij * Cn;
     const int o = nn * s2 + ij;
     dwf[((size_t)o * Cr + c) * 9 + tap] = acc * gscale;
+    orn_flag_nonfinite(sc, acc * gscale);
 }
 
 __global__ void k_wgrad_bf16_reduce(const float *__restrict__ slabs, const float *__restrict__ bias_slabs, int S, int O, int Cn,
@@ -901,13 +909,13 @@ __global__ void k_wgrad_bf16_reduce(const float *__restrict__ slabs, const float
 // Every fast layer's reduction in one launch at the end of the backward (blockIdx.y = layer): four graph nodes of 6-26 us
 // that each started cold become one that keeps the whole chip streaming.
 struct WgradReduceAll {
-    struct { const float *slabs, *bias_slabs; int S, O, Cn, s2, Cr; float gscale; float *dwf, *dbf; } l[ORN_MAX_LAYERS];
+    struct { const float *slabs, *bias_slabs; int S, O, Cn, s2, Cr; float gscale; float *dwf, *dbf; OrnScaleState *sc; } l[ORN_MAX_LAYERS];
 };
 __global__ void k_wgrad_bf16_reduce_all(WgradReduceAll a)
 {
     const auto &l = a.l[blockIdx.y];
     if ((size_t)blockIdx.x * blockDim.x >= (size_t)9 * l.O * 96) return;
-    wgrad_reduce_body(l.slabs, l.bias_slabs, l.S, l.O, l.Cn, l.s2, l.Cr, l.gscale, l.dwf, l.dbf);
+    wgrad_reduce_body(l.slabs, l.bias_slabs, l.S, l.O, l.Cn, l.s2, l.Cr, l.gscale, l.dwf, l.dbf, l.sc);
 }
 
 int orn_wgrad_bf16_split(int H, int W, int O)
@@ -1002,7 +1010,7 @@ int orn_launch_wgrad_reduce_all(int n, const OrnWgradReduce *L, hipStream_t st)
         const int S = orn_wgrad_bf16_split(L[i].H, L[i].W, L[i].O), s2 = L[i].s * L[i].s;
         a.l[i].slabs = L[i].slabs; a.l[i].bias_slabs = L[i].slabs + (size_t)S * 9 * L[i].O * 96;
         a.l[i].S = S; a.l[i].O = L[i].O; a.l[i].Cn = L[i].O / s2; a.l[i].s2 = s2; a.l[i].Cr = L[i].C; a.l[i].gscale = L[i].gscale;
-        a.l[i].dwf = L[i].dwf; a.l[i].dbf = L[i].dbf;
+        a.l[i].dwf = L[i].dwf; a.l[i].dbf = L[i].dbf; a.l[i].sc = L[i].sc;
         const size_t w = (size_t)9 * L[i].O * 96;
         if (w > mx) mx = w;
     }
@@ -1120,8 +1128,9 @@ __global__ void __launch_bounds__(256) k_nchw_to_nhwc_pad_bf16(const float *__re
 
 // fp32 NHWC slabs [nslab][H][W][Cp] -> fp32 NCHW [C][H][W], C <= Cp (sum over slabs in fixed order), tiled through LDS
 __global__ void __launch_bounds__(256) k_nhwc_to_nchw_f32(const float *__restrict__ src, int C, int Cp, int H, int W, int nslab,
-                                                         float scale, float *__restrict__ dst)
+                                                         float scale, float *__restrict__ dst, const OrnScaleState *sc)
 {
+    if (sc) scale = sc->inv_gs;
     __shared__ float tile[TR_MAXC][TR_PX + 1];
     const size_t HW = (size_t)H * W, n = HW * Cp;
     const size_t p0 = (size_t)blockIdx.x * TR_PX;
@@ -1147,10 +1156,11 @@ int orn_launch_nchw_to_nhwc_pad_bf16(const float *src, int C, int Cp, int H, int
     return 0;
 }
 
-int orn_launch_nhwc_to_nchw_f32(const float *src, int C, int Cp, int H, int W, int nslab, float scale, float *dst, hipStream_t st)
+int orn_launch_nhwc_to_nchw_f32(const float *src, int C, int Cp, int H, int W, int nslab, float scale, float *dst, hipStream_t st,
+                                const OrnScaleState *sc = nullptr)
 {
     ORN_REQUIRE(C <= TR_MAXC && C <= Cp, "nhwc_to_nchw: C=%d > %d or > stride %d", C, TR_MAXC, Cp);
-    hipLaunchKernelGGL(k_nhwc_to_nchw_f32, dim3(orn_cdiv((long)H * W, TR_PX)), dim3(256), 0, st, src, C, Cp, H, W, nslab, scale, dst);
+    hipLaunchKernelGGL(k_nhwc_to_nchw_f32, dim3(orn_cdiv((long)H * W, TR_PX)), dim3(256), 0, st, src, C, Cp, H, W, nslab, scale, dst, sc);
     ORN_LAUNCH_CHECK("nhwc_to_nchw_f32");
     return 0;
 }
@@ -1281,8 +1291,9 @@ template <int NQ>
 __global__ void __launch_bounds__(256)
 k_head_bwd_nhwc_bf16(const h16 *__restrict__ z, const float *__restrict__ w, const float *__restrict__ out,
                      const float *__restrict__ dout, int H, int W, int sigmoid, int sp, float gs_up, h16 *__restrict__ dypad,
-                     float *__restrict__ partial)
+                     float *__restrict__ partial, const OrnScaleState *sc)
 {
+    if (sc) gs_up = sc->gs;                          // engine: the scale lives in device memory (dynamic loss scaling)
     constexpr int C = NQ * 32;
     __shared__ float sw[3 * C];
     __shared__ float sred[4][4][NQ * 24 + 3];
@@ -1405,7 +1416,7 @@ int orn_head_bwd_bf16_blocks(int H, int W) { const int b = orn_cdiv((long)H * W,
 
 // gs_up: gradient scale carried by dypad (1 for bf16, 2^20 for fp16); dw/db are un-scaled here
 int orn_launch_head_bwd_bf16(const h16 *z, const float *w, const float *out, const float *dout, int C, int H, int W, int sigmoid,
-                             int sp, float gs_up, h16 *dypad, float *dw, float *db, float *ws, hipStream_t st)
+                             int sp, float gs_up, h16 *dypad, float *dw, float *db, float *ws, hipStream_t st, const OrnScaleState *sc = nullptr)
 {
     ORN_REQUIRE(C == 96 || C == 32 || C == 64 || C == 128, "head_bwd_bf16: unsupported C=%d", C);
     ORN_REQUIRE(H % sp == 0 && W % sp == 0, "head_bwd_bf16: H,W not divisible by stride");
@@ -1413,10 +1424,10 @@ int orn_launch_head_bwd_bf16(const h16 *z, const float *w, const float *out, con
     if (blocks > HB_BLOCKS) blocks = HB_BLOCKS;
     float *partial = ws, *red = ws + (size_t)HB_BLOCKS * (3 * C + 3);
     switch (C) {
-    case 32: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<1>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, gs_up, dypad, partial); break;
-    case 64: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<2>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, gs_up, dypad, partial); break;
-    case 96: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<3>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, gs_up, dypad, partial); break;
-    default: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<4>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, gs_up, dypad, partial); break;
+    case 32: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<1>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, gs_up, dypad, partial, sc); break;
+    case 64: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<2>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, gs_up, dypad, partial, sc); break;
+    case 96: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<3>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, gs_up, dypad, partial, sc); break;
+    default: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<4>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, gs_up, dypad, partial, sc); break;
     }
     ORN_LAUNCH_CHECK("head_bwd_bf16");
     if (!dw) return 0;                  // deferred: rides along orn_launch_wgrad_bf16_batch (OrnHeadFinish)
@@ -1439,19 +1450,26 @@ static int a_wgrad(const void *xpad, const void *dypad, int H, int W, int C, int
 { return orn_launch_wgrad_bf16((const h16 *)xpad, (const h16 *)dypad, H, W, C, O, s, gscale, slabs, dwf, dbf, st); }
 static int a_to_nhwc(const float *src, int C, int Cp, int H, int W, void *dst, hipStream_t st)
 { return orn_launch_nchw_to_nhwc_pad_bf16(src, C, Cp, H, W, (h16 *)dst, st); }
+static int a_to_nchw_f32(const float *src, int C, int Cp, int H, int W, int nslab, float scale, float *dst, hipStream_t st, const OrnScaleState *sc)
+{ return orn_launch_nhwc_to_nchw_f32(src, C, Cp, H, W, nslab, scale, dst, st, sc); }
 static int a_head_fwd(const void *z, const float *w, const float *b, int C, size_t HW, int sigmoid, float *out, hipStream_t st)
 { return orn_launch_head_fwd_bf16((const h16 *)z, w, b, C, HW, sigmoid, out, st); }
 static int a_head_bwd(const void *z, const float *w, const float *out, const float *dout, int C, int H, int W, int sigmoid, int sp,
-                      float gs_up, void *dypad, float *dw, float *db, float *ws, hipStream_t st)
-{ return orn_launch_head_bwd_bf16((const h16 *)z, w, out, dout, C, H, W, sigmoid, sp, gs_up, (h16 *)dypad, dw, db, ws, st); }
+                      float gs_up, void *dypad, float *dw, float *db, float *ws, hipStream_t st, const OrnScaleState *sc)
+{ return orn_launch_head_bwd_bf16((const h16 *)z, w, out, dout, C, H, W, sigmoid, sp, gs_up, (h16 *)dypad, dw, db, ws, st, sc); }
 
 const OrnHalfOps ops = {a_conv_fwd, a_conv_dgrad, orn_wgrad_bf16_ws_floats, a_wgrad, orn_launch_wgrad_bf16_batch, orn_launch_wgrad_reduce_all, orn_launch_prep_weights_bf16_all, a_to_nhwc,
-                        orn_launch_nhwc_to_nchw_f32, orn_dgrad_f32_slabs, a_head_fwd, orn_head_bwd_bf16_ws_floats, orn_head_bwd_bf16_blocks, a_head_bwd};
+                        a_to_nchw_f32, orn_dgrad_f32_slabs, a_head_fwd, orn_head_bwd_bf16_ws_floats, orn_head_bwd_bf16_blocks, a_head_bwd};
 
-#ifndef ORN_FP16
 // ================================================================================================
-// test / per-op hooks: the bf16 block on PyTorch-layout fp32 tensors (conversions included)
+// test / per-op hooks: the 16-bit block on PyTorch-layout fp32 tensors (conversions included).  Built in both element
+// types: the bf16 build exports orn_*_bf16, the IEEE-half build the orn_*_f16 twins (same arguments, half buffers).
 // ================================================================================================
+#ifdef ORN_FP16
+#define HOOK(bf16_, f16_) f16_
+#else
+#define HOOK(bf16_, f16_) bf16_
+#endif
 // bf16 NHWC [H][W][C] (optionally padded source) -> fp32 NCHW
 __global__ void k_nhwc_bf16_to_nchw_f32(const h16 *__restrict__ src, int C, int H, int W, int pad, float *__restrict__ dst)
 {
@@ -1485,6 +1503,9 @@ __global__ void k_make_dy_bf16(const float *__restrict__ z, const float *__restr
 
 static inline size_t alh(size_t halfs) { return orn_align(halfs * 2) / 2; }
 
+#ifdef ORN_FP16
+extern "C" size_t orn_conv3x3_ps_silu_bf16_ws_bytes(int C, int O, int H, int W, int s);     // element size is the same: one definition
+#else
 extern "C" size_t orn_conv3x3_ps_silu_bf16_ws_bytes(int C, int O, int H, int W, int s)
 {
     const size_t Hs = (size_t)H * s, Ws = (size_t)W * s, Cn = O / (s * s);
@@ -1500,6 +1521,7 @@ extern "C" size_t orn_conv3x3_ps_silu_bf16_ws_bytes(int C, int O, int H, int W, 
     b += orn_align((size_t)H * W * C * 4 * 8);            // dx fp32 NHWC (up to 8 chunk slabs)
     return b;
 }
+#endif
 
 struct Bf16Ws {
     h16 *xpad, *wb, *wd, *zb, *apad, *dypad;
@@ -1526,7 +1548,7 @@ static Bf16Ws carve_bf16(void *ws, int C, int O, int H, int W, int s)
 
 // Same contract as orn_conv3x3_ps_silu_fwd (B = 1) but computed on the bf16 MFMA path.
 // `ws` must be zero-filled by the caller before the first use (the padded borders are never written).
-extern "C" int orn_conv3x3_ps_silu_fwd_bf16(const float *x, const float *wf, const float *bf, int C, int O, int H, int W,
+extern "C" int HOOK(orn_conv3x3_ps_silu_fwd_bf16, orn_conv3x3_ps_silu_fwd_f16)(const float *x, const float *wf, const float *bf, int C, int O, int H, int W,
                                             int s, float *z, float *a, void *ws, size_t ws_bytes, void *stream)
 {
     ORN_REQUIRE(x && wf && bf && a && ws, "conv3x3_ps_silu_fwd_bf16: null pointer");
@@ -1545,7 +1567,7 @@ extern "C" int orn_conv3x3_ps_silu_fwd_bf16(const float *x, const float *wf, con
     return 0;
 }
 
-extern "C" int orn_conv3x3_ps_silu_bwd_bf16(const float *x, const float *wf, const float *z, const float *da, int C, int O,
+extern "C" int HOOK(orn_conv3x3_ps_silu_bwd_bf16, orn_conv3x3_ps_silu_bwd_f16)(const float *x, const float *wf, const float *z, const float *da, int C, int O,
                                             int H, int W, int s, float *dx, float *dwf, float *dbf, void *ws,
                                             size_t ws_bytes, void *stream)
 {
@@ -1569,7 +1591,7 @@ extern "C" int orn_conv3x3_ps_silu_bwd_bf16(const float *x, const float *wf, con
 }
 
 // Raw channels-last entry points (the engine's own layouts; used by bench.py's roofline leg).
-extern "C" int orn_conv_nhwc_bf16_fwd(const void *xpad, const void *wb, const float *bias_p, int H, int W, int C, int O,
+extern "C" int HOOK(orn_conv_nhwc_bf16_fwd, orn_conv_nhwc_f16_fwd)(const void *xpad, const void *wb, const float *bias_p, int H, int W, int C, int O,
                                       int s, void *z, void *apad, void *stream)
 {
     ORN_REQUIRE(xpad && wb && z, "conv_nhwc_bf16_fwd: null pointer");
@@ -1577,26 +1599,35 @@ extern "C" int orn_conv_nhwc_bf16_fwd(const void *xpad, const void *wb, const fl
                                     (hipStream_t)stream, C);
 }
 
-extern "C" int orn_wgrad_nhwc_bf16(const void *xpad, const void *dypad, int H, int W, int C, int O, int s, float *slabs,
+extern "C" int HOOK(orn_wgrad_nhwc_bf16, orn_wgrad_nhwc_f16)(const void *xpad, const void *dypad, int H, int W, int C, int O, int s, float *slabs,
                                    float *dwf, float *dbf, void *stream)
 {
     return orn_launch_wgrad_bf16((const h16 *)xpad, (const h16 *)dypad, H, W, C, O, s, 1.0f, slabs, dwf, dbf, (hipStream_t)stream);
 }
+#ifndef ORN_FP16
 extern "C" size_t orn_wgrad_nhwc_bf16_ws_bytes(int H, int W, int O) { return orn_wgrad_bf16_ws_floats(H, W, O) * 4; }
-extern "C" int orn_dgrad_nhwc_bf16(const void *dypad, const void *wd, int H, int W, int O, int C, const void *zprev,
+#endif
+extern "C" int HOOK(orn_dgrad_nhwc_bf16, orn_dgrad_nhwc_f16)(const void *dypad, const void *wd, int H, int W, int O, int C, const void *zprev,
                                    void *dyprev, int sp, void *stream)
 {
     return orn_launch_conv_bf16_dgrad((const h16 *)dypad, (const h16 *)wd, H, W, O, C, (const h16 *)zprev, (h16 *)dyprev, sp,
                                       nullptr, (hipStream_t)stream, C);
 }
 
-extern "C" void orn_debug_set(int flags) { set_debug(flags); }   // timing experiments only (tools/probes)
 #ifdef ORN_CONV_STAMP
-extern "C" void orn_debug_set_stamps(void *buf) { g_conv_stamps = (unsigned long long *)buf; }
+void set_stamps(void *buf) { g_conv_stamps = (unsigned long long *)buf; }
 #endif
-#endif  // !ORN_FP16
 
 }  // namespace HNS
+
+#ifndef ORN_FP16
+// probe-only switches (include/orn_debug.h) reach both builds
+namespace orn_f16 { void set_debug(int flags); void set_stamps(void *buf); }
+extern "C" void orn_debug_set(int flags) { orn_bf16::set_debug(flags); orn_f16::set_debug(flags); }
+#ifdef ORN_CONV_STAMP
+extern "C" void orn_debug_set_stamps(void *buf) { orn_bf16::set_stamps(buf); orn_f16::set_stamps(buf); }
+#endif
+#endif
 
 const OrnHalfOps *
 #ifdef ORN_FP16

@@ -1,6 +1,6 @@
 // Small HBM-/latency-bound kernels of the hot path: positional encoding (A1), MLP stem (A2),
 // 1x1 head (A5), Adam (A9) and the deterministic reduction helpers everything else shares.
-#include "orn_common.h"
+#include "orn_internal.h"
 #include <math.h>
 #include <string.h>
 
@@ -509,8 +509,14 @@ extern "C" int orn_head_bwd(const float *a, const float *w, const float *out, co
 template <bool MASK>
 __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
                        size_t n, float step_size_v, float sqrt_bc2_v, const OrnStepCur *__restrict__ sp, float beta1,
-                       float omb1, float beta2, float omb2, float eps, float inv_gscale, const float *__restrict__ gmask)
+                       float omb1, float beta2, float omb2, float eps, float inv_gscale, const float *__restrict__ gmask,
+                       OrnScaleState *sc)
 {
+    // non-finite gradients somewhere in this step: leave parameters and moments alone (the whole step is skipped)
+    if (sc && sc->flag) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) sc->skipped += 1;
+        return;
+    }
     // gmask (optional, 0/1 per parameter): the gradient is multiplied by it -- the prune fine-tune of main_eval.py,
     // where a masked weight (weight_orig * mask) only ever receives the masked gradient and a frozen tensor none
     float step_size = step_size_v, sqrt_bc2 = sqrt_bc2_v;
@@ -547,16 +553,16 @@ __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float
 }
 
 int orn_launch_adam(float *p, const float *g, float *m, float *v, size_t n, double lr, int step, const OrnStepCur *sp,
-                    double beta1, double beta2, double eps, float inv_gscale, hipStream_t st, const float *gmask)
+                    double beta1, double beta2, double eps, float inv_gscale, hipStream_t st, const float *gmask, OrnScaleState *sc)
 {
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     const dim3 gr(orn_cdiv((long)orn_cdiv((long)n, 4), 256));
     if (gmask)
         hipLaunchKernelGGL(k_adam<true>, gr, dim3(256), 0, st, p, g, m, v, n, (float)(lr / bc1), (float)sqrt(bc2), sp, (float)beta1,
-                           (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, inv_gscale, gmask);
+                           (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, inv_gscale, gmask, sc);
     else
         hipLaunchKernelGGL(k_adam<false>, gr, dim3(256), 0, st, p, g, m, v, n, (float)(lr / bc1), (float)sqrt(bc2), sp, (float)beta1,
-                           (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, inv_gscale, gmask);
+                           (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, inv_gscale, gmask, sc);
     ORN_LAUNCH_CHECK("adam");
     return 0;
 }

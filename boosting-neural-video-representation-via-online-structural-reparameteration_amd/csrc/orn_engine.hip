@@ -38,7 +38,8 @@ struct orn_engine {
     LayerBuf L[ORN_MAX_LAYERS];
     int Hout, Wout, Cn_last;
     const OrnHalfOps *ops;           // 16-bit fast-path kernels (bf16 or fp16 build)
-    float gs;                        // gradient scale carried by the 16-bit gradient tensors (1 for bf16, 2^20 for fp16)
+    float gs;                        // INITIAL gradient scale of the 16-bit gradient tensors (1 for bf16, 2^20 for fp16)
+    OrnScaleState *sc;               // device: the live scale + non-finite flag (dynamic loss scaling, skipped steps)
     void *merge_tables;              // device-resident grouped-GEMM problem tables (ERB)
     void *mh_tables, *mh_host;       // 16-bit modes: tables of the packed-operand merge backward (device / host)
     int merge_tiles[4];
@@ -55,7 +56,7 @@ struct orn_engine {
     hipStream_t g_stream;
     // orn_engine_profile_step: HIP events around every forward conv launch of an eager step
     bool prof;
-    hipEvent_t prof_ev[2 * ORN_MAX_LAYERS];
+    hipEvent_t prof_ev[4 * ORN_MAX_LAYERS + 4];      // pairs: forward conv of layer i, dgrad launch of layer i, wgrad batch, its reduction
 };
 
 #define ORN_GRAPH_UNROLL 4
@@ -173,12 +174,14 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
     float *scr = take(scratch);
     float *head_ws = (ff < d->n_layers) ? take(orn_half_ops_bf16()->head_bwd_ws_floats(Cn)) : nullptr;
     float *cur = take((sizeof(OrnStepCur) * ORN_GRAPH_UNROLL + 3) / 4 + 16);    // one cursor state per step of the unrolled graph
+    float *scs = take(sizeof(OrnScaleState) / 4);
     float *mtab = d->erb ? take(orn_merge_group_bytes() / 4) : nullptr;
     float *mhtab = (d->erb && d->precision != 0) ? take(orn_merge_h16_table_bytes() / 4) : nullptr;
     if (e) {
         e->pre1 = pre1; e->h1 = h1; e->pre2 = pre2; e->h2 = h2; e->dh2 = dh2;
         e->img = img; e->dimg = dimg; e->stats = stats; e->loss_ws = loss_ws; e->scratch = scr; e->head_ws = head_ws;
         e->cur = (OrnStepCur *)cur;
+        e->sc = (OrnScaleState *)scs;
         for (int i = 0; i < d->n_layers; ++i) e->L[i] = L[i];
         e->Hout = H; e->Wout = W; e->Cn_last = Cn;
         e->ff = ff; e->dxn = dxn;
@@ -219,7 +222,7 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
     e->graph = nullptr; e->graph_exec = nullptr; e->graph_u = nullptr; e->graph_exec_u = nullptr;
     e->prof = false;
     e->mh_host = nullptr;
-    for (int i = 0; i < 2 * ORN_MAX_LAYERS; ++i) e->prof_ev[i] = nullptr;
+    for (int i = 0; i < 4 * ORN_MAX_LAYERS + 4; ++i) e->prof_ev[i] = nullptr;
     e->ops = (d->precision == 2) ? orn_half_ops_f16() : orn_half_ops_bf16();
     e->gs = (d->precision == 2) ? 1048576.0f : 1.0f;
     layout(d, e);
@@ -227,6 +230,10 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
         hipError_t rc = hipMemset(ws, 0, need);
         if (rc == hipSuccess) rc = hipDeviceSynchronize();
         if (rc != hipSuccess) { orn_set_error("engine_create: hipMemset failed: %s", hipGetErrorString(rc)); delete e; return (int)rc; }
+        OrnScaleState s0 = {};
+        s0.gs = e->gs; s0.inv_gs = 1.0f / e->gs; s0.gs_max = e->gs;
+        rc = hipMemcpy(e->sc, &s0, sizeof(s0), hipMemcpyHostToDevice);
+        if (rc != hipSuccess) { orn_set_error("engine_create: scale state upload failed: %s", hipGetErrorString(rc)); delete e; return (int)rc; }
     }
     if (!d->erb)
         for (int i = 0; i < d->n_layers; ++i) {
@@ -254,7 +261,7 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
             void *bufs[ORN_MAX_LAYERS];
             for (int i = 0; i < d->n_layers; ++i) bufs[i] = e->L[i].mh16;
             e->mh_host = malloc(orn_merge_h16_host_bytes());
-            rc = e->mh_host ? orn_merge_h16_build(e->mh_tables, e->mh_host, d->n_layers, ml, bufs) : ORN_E_ARG;
+            rc = e->mh_host ? orn_merge_h16_build(e->mh_tables, e->mh_host, d->n_layers, ml, bufs, e->sc) : ORN_E_ARG;
         }
         if (rc != 0) { free(e->mh_host); delete e; return rc; }
         for (int k = 0; k < 4; ++k) e->merge_tiles[k] = orn_merge_group_tiles(k, d->n_layers, ml);
@@ -270,7 +277,7 @@ extern "C" void orn_engine_destroy(orn_engine *e)
     if (e->graph) (void)hipGraphDestroy(e->graph);
     if (e->graph_exec_u) (void)hipGraphExecDestroy(e->graph_exec_u);
     if (e->graph_u) (void)hipGraphDestroy(e->graph_u);
-    for (int i = 0; i < 2 * ORN_MAX_LAYERS; ++i)
+    for (int i = 0; i < 4 * ORN_MAX_LAYERS + 4; ++i)
         if (e->prof_ev[i]) (void)hipEventDestroy(e->prof_ev[i]);
     free(e->mh_host);
     delete e;
@@ -290,6 +297,34 @@ extern "C" int orn_engine_set_grad_mask(orn_engine *e, const float *mask)
     return 0;
 }
 
+// Loss-scale state: out8 = {gs, 1/gs, gs_max, flag, skipped, good, backoffs, 0} (host floats; synchronises the device).
+extern "C" int orn_engine_scale_state(orn_engine *e, float *out8)
+{
+    ORN_REQUIRE(e && out8, "engine_scale_state: null pointer");
+    OrnScaleState s;
+    hipError_t rc = hipDeviceSynchronize();
+    if (rc == hipSuccess) rc = hipMemcpy(&s, e->sc, sizeof(s), hipMemcpyDeviceToHost);
+    if (rc != hipSuccess) { orn_set_error("engine_scale_state: %s", hipGetErrorString(rc)); return (int)rc; }
+    out8[0] = s.gs; out8[1] = s.inv_gs; out8[2] = s.gs_max; out8[3] = (float)s.flag; out8[4] = (float)s.skipped;
+    out8[5] = (float)s.good; out8[6] = (float)s.backoffs; out8[7] = 0.f;
+    return 0;
+}
+
+// Overrides the live gradient scale (tests: a scale far too large makes the 16-bit gradients overflow; tuning).  gs_max > 0
+// also replaces the ceiling the scale may grow back to.
+extern "C" int orn_engine_set_grad_scale(orn_engine *e, float gs, float gs_max)
+{
+    ORN_REQUIRE(e && gs >= 1.0f, "engine_set_grad_scale: scale must be >= 1");
+    OrnScaleState s;
+    hipError_t rc = hipDeviceSynchronize();
+    if (rc == hipSuccess) rc = hipMemcpy(&s, e->sc, sizeof(s), hipMemcpyDeviceToHost);
+    s.gs = gs; s.inv_gs = 1.0f / gs; s.good = 0;
+    if (gs_max > 0.f) s.gs_max = gs_max;
+    if (rc == hipSuccess) rc = hipMemcpy(e->sc, &s, sizeof(s), hipMemcpyHostToDevice);
+    if (rc != hipSuccess) { orn_set_error("engine_set_grad_scale: %s", hipGetErrorString(rc)); return (int)rc; }
+    return 0;
+}
+
 extern "C" int orn_engine_fused_kernel(orn_engine *e, int layer, const float **wf, const float **bf)
 {
     ORN_REQUIRE(e && wf && bf && layer >= 0 && layer < e->d.n_layers, "engine_fused_kernel: bad arguments");
@@ -301,14 +336,30 @@ extern "C" int orn_engine_fused_kernel(orn_engine *e, int layer, const float **w
 // ------------------------------------------------------------------------------------------------
 // `count` consecutive steps at once (thread j -> cur[j]): the unrolled graph advances once for all its steps
 __global__ void k_advance(const orn_step_sched *__restrict__ sched, int32_t *cursor, int32_t n_slots, double beta1,
-                          double beta2, OrnStepCur *cur_all, int count)
+                          double beta2, OrnStepCur *cur_all, int count, OrnScaleState *sc)
 {
     const int32_t c0 = *cursor;
+    __shared__ int32_t skipped;
+    if (threadIdx.x == 0) {
+        // dynamic loss scale: the steps since the last advance met a non-finite gradient (Adam skipped them) -> halve the
+        // scale; ORN_SCALE_GROWTH_INTERVAL clean steps -> double it again, up to its initial value
+        float gs = sc->gs;
+        if (sc->flag) {
+            gs = fmaxf(gs * 0.5f, 1.0f);
+            sc->flag = 0; sc->good = 0; sc->backoffs += 1;
+        } else {
+            sc->good += count;
+            if (sc->good >= ORN_SCALE_GROWTH_INTERVAL && gs < sc->gs_max) { gs *= 2.0f; sc->good = 0; }
+        }
+        sc->gs = gs; sc->inv_gs = 1.0f / gs;
+        skipped = sc->skipped;
+    }
     __syncthreads();
     if (blockIdx.x == 0 && (int)threadIdx.x < count) {
         const int32_t c = c0 + threadIdx.x;
         OrnStepCur *cur = cur_all + threadIdx.x;
-        const orn_step_sched s = sched[c];
+        orn_step_sched s = sched[c];
+        s.step = max(s.step - skipped, 1);              // torch: a skipped optimizer.step() does not advance Adam's step count
         cur->frame = s.frame;
         cur->step = s.step;
         cur->lr = s.lr;
@@ -395,17 +446,17 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
     const size_t HWo = (size_t)e->Hout * e->Wout;
     OrnStepCur *cur = e->cur + cur_idx;
     if (adv_count > 0) {
-        hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, sched, cursor, n_slots, d.beta1, d.beta2, e->cur, adv_count);
+        hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, sched, cursor, n_slots, d.beta1, d.beta2, e->cur, adv_count, e->sc);
         ORN_LAUNCH_CHECK("advance");
     }
     const int *fidx = &cur->frame;
     ORN_TRY(forward(e, embeds, fidx, true, st));
     ORN_TRY(orn_launch_loss(e->img, frames, fidx, 3 * HWo, 1, 3, e->Hout, e->Wout, d.loss_type, 1.0f, e->stats, e->dimg,
-                            e->loss_ws, st, cur, stats_out));
+                            e->loss_ws, st, cur, stats_out, e->sc));
     const int nl = d.n_layers, ff = e->ff;
     if (ff < nl)
         ORN_TRY(e->ops->head_bwd(e->L[nl - 1].zb, P + d.head_w, e->img, e->dimg, e->Cn_last, e->Hout, e->Wout, d.sigmoid,
-                                 d.layer[nl - 1].s, e->gs, e->L[nl - 1].dypad, nullptr, nullptr, e->head_ws, st));   // dW / db: finished with the wgrad batch
+                                 d.layer[nl - 1].s, e->gs, e->L[nl - 1].dypad, nullptr, nullptr, e->head_ws, st, e->sc));   // dW / db: finished with the wgrad batch
     else
         ORN_TRY(orn_launch_head_bwd(e->L[nl - 1].a, P + d.head_w, e->img, e->dimg, 1, e->Cn_last, HWo, d.sigmoid, e->L[nl - 1].da,
                                     G + d.head_w, G + d.head_b, e->scratch, st));
@@ -415,6 +466,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         const float *x = (i == 0) ? e->h2 : e->L[i - 1].a;
         float *dx = (i == 0) ? e->dh2 : e->L[i - 1].da;
         // dWf / dbf land directly in the 3x3 branch's gradient slots (dW3x3 = dWf, db3x3 = dbf)
+        if (e->prof) (void)hipEventRecord(e->prof_ev[2 * ORN_MAX_LAYERS + 2 * i], st);
         if (i >= ff) {
             // (the wgrads of all fast layers run as one multi-problem launch after the dgrad chain, see below)
             if (i > ff) {
@@ -426,14 +478,15 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
                 ORN_TRY(e->ops->conv_dgrad(b.dypad, b.wd, l.H, l.W, l.O, ORN_FAST_C, nullptr, nullptr, 1, e->dxn, st, l.C));
                 if (!e->stage0)
                 ORN_TRY(e->ops->to_nchw_f32(e->dxn, l.C, ORN_FAST_C, l.H, l.W, e->ops->dgrad_f32_slabs(l.H, l.W, l.O), 1.0f / e->gs, dx,
-                                            st));
+                                            st, e->sc));
             }
         } else if (e->stage0) {
             const orn_layer_desc &l1 = d.layer[1];
             ORN_TRY(orn_launch_stage0_bwd(x, b.wf, b.z, e->dxn, e->ops->dgrad_f32_slabs(l1.H, l1.W, l1.O), ORN_FAST_C, 1.0f / e->gs, l.C, l.O,
-                                          l.H, l.W, l.s, e->scratch + e->stem_ws, nullptr, G + l.w3x3, G + l.b3x3, st));
+                                          l.H, l.W, l.s, e->scratch + e->stem_ws, nullptr, G + l.w3x3, G + l.b3x3, st, e->sc));
         } else
         ORN_TRY(orn_launch_conv_bwd_f32(x, b.wf, b.z, b.da, 1, l.C, l.O, l.H, l.W, l.s, dx, G + l.w3x3, G + l.b3x3, e->scratch, st));
+        if (e->prof) (void)hipEventRecord(e->prof_ev[2 * ORN_MAX_LAYERS + 2 * i + 1], st);
     }
     // stem backward; with a wgrad batch behind it, its last kernel (needed by Adam only) rides along that launch
     OrnStemW0Job w0job;
@@ -452,14 +505,18 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
             const orn_layer_desc &l = d.layer[i];
             wj[nj++] = OrnWgradJob{e->L[i].xpad, e->L[i].dypad, l.H, l.W, l.C, l.O, l.s, e->L[i].wslab};
         }
-        const OrnHeadFinish hf = {e->head_ws, e->ops->head_bwd_blocks(e->Hout, e->Wout), e->Cn_last, 1.0f / e->gs, G + d.head_w, G + d.head_b};
+        const OrnHeadFinish hf = {e->head_ws, e->ops->head_bwd_blocks(e->Hout, e->Wout), e->Cn_last, 1.0f / e->gs, G + d.head_w, G + d.head_b, e->sc};
+        if (e->prof) (void)hipEventRecord(e->prof_ev[4 * ORN_MAX_LAYERS], st);
         ORN_TRY(e->ops->wgrad_batch(nj, wj, st, &hf, &w0job));
+        if (e->prof) (void)hipEventRecord(e->prof_ev[4 * ORN_MAX_LAYERS + 1], st);
         OrnWgradReduce wr[ORN_MAX_LAYERS];
         for (int i = ff; i < nl; ++i) {
             const orn_layer_desc &l = d.layer[i];
-            wr[i - ff] = OrnWgradReduce{e->L[i].wslab, l.H, l.W, l.C, l.O, l.s, 1.0f / e->gs, G + l.w3x3, G + l.b3x3};
+            wr[i - ff] = OrnWgradReduce{e->L[i].wslab, l.H, l.W, l.C, l.O, l.s, 1.0f / e->gs, G + l.w3x3, G + l.b3x3, e->sc};
         }
+        if (e->prof) (void)hipEventRecord(e->prof_ev[4 * ORN_MAX_LAYERS + 2], st);
         ORN_TRY(e->ops->wgrad_reduce_all(nl - ff, wr, st));
+        if (e->prof) (void)hipEventRecord(e->prof_ev[4 * ORN_MAX_LAYERS + 3], st);
     }
     if (d.erb) {
         // merge backward of every layer (closed forms): dW3 & dT, then dW2 & dW1, then the slices
@@ -481,7 +538,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         }
         ORN_TRY(orn_launch_merge_bwd_tail_all(nl, mm, st));
     }
-    ORN_TRY(orn_launch_adam(P, G, e->m, e->v, (size_t)d.n_params, 0.0, 1, cur, d.beta1, d.beta2, d.eps, 1.0f, st, e->gmask));
+    ORN_TRY(orn_launch_adam(P, G, e->m, e->v, (size_t)d.n_params, 0.0, 1, cur, d.beta1, d.beta2, d.eps, 1.0f, st, e->gmask, e->sc));
     return 0;
 }
 
@@ -503,7 +560,7 @@ extern "C" int orn_engine_profile_step(orn_engine *e, const float *frames, const
     ORN_REQUIRE(e->grads && e->m && e->v, "engine_profile_step: engine was created without grads / Adam arenas");
     hipStream_t st = (hipStream_t)stream;
     const int nl = e->d.n_layers;
-    for (int i = 0; i < 2 * nl; ++i)
+    for (int i = 0; i < 4 * ORN_MAX_LAYERS + 4; ++i)
         if (!e->prof_ev[i]) {
             hipError_t rc = hipEventCreate(&e->prof_ev[i]);
             if (rc != hipSuccess) { orn_set_error("engine_profile_step: hipEventCreate: %s", hipGetErrorString(rc)); return (int)rc; }
@@ -514,11 +571,22 @@ extern "C" int orn_engine_profile_step(orn_engine *e, const float *frames, const
     if (trc != 0) return trc;
     hipError_t rc = hipStreamSynchronize(st);
     if (rc != hipSuccess) { orn_set_error("engine_profile_step: sync: %s", hipGetErrorString(rc)); return (int)rc; }
-    for (int i = 0; i < nl; ++i) {
+    auto span = [&](int a, float *out) -> int {
         float ms = 0.f;
-        rc = hipEventElapsedTime(&ms, e->prof_ev[2 * i], e->prof_ev[2 * i + 1]);
-        if (rc != hipSuccess) { orn_set_error("engine_profile_step: elapsed: %s", hipGetErrorString(rc)); return (int)rc; }
-        ms_out[i] = ms;
+        hipError_t r = hipEventElapsedTime(&ms, e->prof_ev[a], e->prof_ev[a + 1]);
+        if (r != hipSuccess) { orn_set_error("engine_profile_step: elapsed: %s", hipGetErrorString(r)); return (int)r; }
+        *out = ms;
+        return 0;
+    };
+    const bool fast = e->ff < nl;
+    for (int i = 0; i < nl; ++i) {
+        ORN_TRY(span(2 * i, &ms_out[i]));
+        ORN_TRY(span(2 * ORN_MAX_LAYERS + 2 * i, &ms_out[nl + i]));
+    }
+    ms_out[2 * nl] = ms_out[2 * nl + 1] = 0.f;
+    if (fast) {
+        ORN_TRY(span(4 * ORN_MAX_LAYERS, &ms_out[2 * nl]));
+        ORN_TRY(span(4 * ORN_MAX_LAYERS + 2, &ms_out[2 * nl + 1]));
     }
     return 0;
 }
@@ -562,13 +630,4 @@ extern "C" int orn_engine_train_steps_graph(orn_engine *e, const float *frames, 
         left -= big ? ORN_GRAPH_UNROLL : 1;
     }
     return 0;
-}
-
-// The forward conv kernel of the IEEE-half build on raw channels-last buffers (bench.py's roofline leg; the bf16
-// twin orn_conv_nhwc_bf16_fwd lives next to the kernels).
-extern "C" int orn_conv_nhwc_f16_fwd(const void *xpad, const void *wb, const float *bias_p, int H, int W, int C, int O,
-                                     int s, void *z, void *apad, void *stream)
-{
-    ORN_REQUIRE(xpad && wb && z, "conv_nhwc_f16_fwd: null pointer");
-    return orn_half_ops_f16()->conv_fwd(xpad, wb, bias_p, H, W, C, O, s, z, apad, (hipStream_t)stream, C);
 }

@@ -16,7 +16,8 @@ int orn_launch_head_fwd(const float *a, const float *w, const float *b, int B, i
 int orn_launch_head_bwd(const float *a, const float *w, const float *out, const float *dout, int B, int C, size_t HW,
                         int sigmoid, float *da, float *dw, float *db, float *ws, hipStream_t st);
 int orn_launch_adam(float *p, const float *g, float *m, float *v, size_t n, double lr, int step, const OrnStepCur *sp,
-                    double beta1, double beta2, double eps, float inv_gscale, hipStream_t st, const float *gmask = nullptr);
+                    double beta1, double beta2, double eps, float inv_gscale, hipStream_t st, const float *gmask = nullptr,
+                    OrnScaleState *sc = nullptr);   // sc: skip the update while its flag is up
 
 // orn_stage0.hip: the fp32 block below the first 16-bit one (tiny stem image), forward / backward as one launch each
 bool orn_stage0_supported(int C, int O, int H, int W, int s);
@@ -24,7 +25,8 @@ int orn_stage0_slabs(int O, int s);
 int orn_launch_stage0_fwd(const float *x, const float *wf, const float *bf, int C, int O, int H, int W, int s, float *z,
                           void *xpad_next, int Cp, int precision, hipStream_t st);
 int orn_launch_stage0_bwd(const float *x, const float *wf, const float *z, const float *dxn, int nslab, int Cp, float inv_gs, int C,
-                          int O, int H, int W, int s, float *slabs, float *dx, float *dwf, float *dbf, hipStream_t st);
+                          int O, int H, int W, int s, float *slabs, float *dx, float *dwf, float *dbf, hipStream_t st,
+                          const OrnScaleState *sc = nullptr);   // sc: 1/scale from the device state instead of inv_gs
 
 // orn_merge.hip
 int orn_launch_merge_fwd(const float *w3x3, const float *b3x3, const float *w3x1, const float *b3x1,
@@ -57,7 +59,7 @@ int orn_launch_merge_bwd_tail(const float *g, const float *dbf, int C, int O, fl
 size_t orn_merge_h16_layer_halfs(int C, int O);
 size_t orn_merge_h16_table_bytes();
 size_t orn_merge_h16_host_bytes();
-int orn_merge_h16_build(void *dev_tables, void *host, int n_layers, const OrnMergeLayer *L, void *const *bufs);
+int orn_merge_h16_build(void *dev_tables, void *host, int n_layers, const OrnMergeLayer *L, void *const *bufs, OrnScaleState *sc);
 int orn_launch_merge_h16_bwd(const void *dev_tables, const void *host, hipStream_t st);
 
 // per-layer elementwise tails of the merge, all layers per launch
@@ -81,15 +83,15 @@ int orn_launch_conv_bwd_f32(const float *x, const float *wf, const float *z, con
 int orn_loss_init();
 int orn_launch_loss(const float *pred, const float *target, const int *frame_idx, size_t frame_stride, int B, int Ch,
                     int H, int W, int loss_type, float loss_scale, float *stats, float *dpred, float *ws,
-                    hipStream_t st, const OrnStepCur *cur = nullptr, float *ring = nullptr);
+                    hipStream_t st, const OrnStepCur *cur = nullptr, float *ring = nullptr, OrnScaleState *sc = nullptr);
 
 // orn_conv_bf16.hip: the 16-bit MFMA fast path (channels-last buffers, see the file header).  The file is built
 // twice (bf16 and, with -DORN_FP16, IEEE half); the engine reaches either build through this type-erased table.
 struct OrnPrepLayer { const float *wf, *bf; int O, C, s; void *wb, *wd; float *biasp; int Cp; };   // Cp: channel stride (0: = C)
 // deferred split-K reduction of a layer's wgrad slabs (wgrad called with dwf == nullptr leaves them in `slabs`)
-struct OrnWgradReduce { const float *slabs; int H, W, C, O, s; float gscale; float *dwf, *dbf; };
+struct OrnWgradReduce { const float *slabs; int H, W, C, O, s; float gscale; float *dwf, *dbf; OrnScaleState *sc; };   // sc (optional): 1/scale from the device state, non-finite results raise its flag
 // deferred reduction of the 16-bit head backward's per-block partials (head_bwd called with dw == nullptr leaves them in ws)
-struct OrnHeadFinish { const float *partial; int blocks, C; float gscale; float *dw, *db; };
+struct OrnHeadFinish { const float *partial; int blocks, C; float gscale; float *dw, *db; OrnScaleState *sc; };
 struct OrnWgradJob { const void *xpad, *dypad; int H, W, C, O, s; float *slabs; };   // wgrad into slabs, reduction deferred
 struct OrnHalfOps {
     int (*conv_fwd)(const void *xpad, const void *wb, const float *bias_p, int H, int W, int Cin, int O, int s, void *z, void *apad,
@@ -103,13 +105,13 @@ struct OrnHalfOps {
     int (*wgrad_reduce_all)(int n, const OrnWgradReduce *L, hipStream_t st);   // all layers' reductions in one launch
     int (*prep_all)(int n, const OrnPrepLayer *L, hipStream_t st);
     int (*to_nhwc)(const float *src, int C, int Cp, int H, int W, void *dst, hipStream_t st);
-    int (*to_nchw_f32)(const float *src, int C, int Cp, int H, int W, int nslab, float scale, float *dst, hipStream_t st);
+    int (*to_nchw_f32)(const float *src, int C, int Cp, int H, int W, int nslab, float scale, float *dst, hipStream_t st, const OrnScaleState *sc);
     int (*dgrad_f32_slabs)(int H, int W, int O);
     int (*head_fwd)(const void *z, const float *w, const float *b, int C, size_t HW, int sigmoid, float *out, hipStream_t st);
     size_t (*head_bwd_ws_floats)(int C);
     int (*head_bwd_blocks)(int H, int W);
     int (*head_bwd)(const void *z, const float *w, const float *out, const float *dout, int C, int H, int W, int sigmoid, int sp,
-                    float gs_up, void *dypad, float *dw, float *db, float *ws, hipStream_t st);
+                    float gs_up, void *dypad, float *dw, float *db, float *ws, hipStream_t st, const OrnScaleState *sc);   // sc: gs from the device state
 };
 const OrnHalfOps *orn_half_ops_bf16();
 const OrnHalfOps *orn_half_ops_f16();

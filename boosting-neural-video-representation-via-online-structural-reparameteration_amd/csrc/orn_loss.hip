@@ -6,7 +6,7 @@
 //                  (p-t)^2 sums
 // followed by a fixed-order finalize.  SSIM follows pytorch_msssim 0.2.1's published algorithm
 // (the package is not in the reference tree: parity unpinned, see oracle/cpu_ref.py).
-#include "orn_common.h"
+#include "orn_internal.h"
 
 #define SS_TH 16
 #define SS_TW 64
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(256) k_loss_grad(LossP q)
 __global__ void __launch_bounds__(1024)
 k_loss_finalize(const float *__restrict__ part_ssim, int n_ssim, const float *__restrict__ part_l1, int n_l1,
                 double n_elem, double n_map, int loss_type, float loss_scale, float *__restrict__ stats,
-                const OrnStepCur *__restrict__ cur, float *__restrict__ ring)
+                const OrnStepCur *__restrict__ cur, float *__restrict__ ring, OrnScaleState *sc)
 {
     __shared__ double sd[3][1024];
     const int t = threadIdx.x;
@@ -262,6 +262,7 @@ k_loss_finalize(const float *__restrict__ part_ssim, int n_ssim, const float *__
         if (loss_type == ORN_LOSS_L2) loss = mse;
         else if (loss_type == ORN_LOSS_L1) loss = l1;
         else loss = 0.7f * l1 + 0.3f * (1.0f - ss);
+        orn_flag_nonfinite(sc, loss);                // a NaN / inf forward pass: no update from this step
         stats[0] = loss * loss_scale;
         stats[1] = l1;
         stats[2] = mse;
@@ -324,7 +325,7 @@ extern "C" size_t orn_loss_ws_bytes(int B, int Ch, int H, int W) { return loss_g
 
 int orn_launch_loss(const float *pred, const float *target, const int *frame_idx, size_t frame_stride, int B, int Ch,
                     int H, int W, int loss_type, float loss_scale, float *stats, float *dpred, float *ws,
-                    hipStream_t st, const OrnStepCur *cur, float *ring)
+                    hipStream_t st, const OrnStepCur *cur, float *ring, OrnScaleState *sc)
 {
     ORN_REQUIRE(loss_type == ORN_LOSS_L2 || loss_type == ORN_LOSS_L1 || loss_type == ORN_LOSS_FUSION6,
                 "loss: unsupported loss_type %d", loss_type);
@@ -357,7 +358,7 @@ int orn_launch_loss(const float *pred, const float *target, const int *frame_idx
     }
     ORN_LAUNCH_CHECK("loss_grad");
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, st, q.part_ssim, n_ssim, q.part_l1, g.planes * g.tw * g.th, n,
-                       (double)g.nmap, loss_type, loss_scale, stats, cur, ring);
+                       (double)g.nmap, loss_type, loss_scale, stats, cur, ring, sc);
     ORN_LAUNCH_CHECK("loss_finalize");
     return 0;
 }

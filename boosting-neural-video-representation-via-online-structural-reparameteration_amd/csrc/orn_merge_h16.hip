@@ -63,6 +63,7 @@ struct MhPackAll {
     int n;
     int blk_start[MH_JOBS * ORN_MAX_LAYERS + 1];   // 1-D grid: block ranges of the (layer, job) pairs, job-major within a layer
     MhPackLayer l[ORN_MAX_LAYERS];
+    OrnScaleState *sc;   // optional: an overflow of the scaled half copy of G raises its flag (the step is then skipped)
 };
 
 // job 0: G -> Gh (x 2^14);  1: T -> Th;  2: W1 -> W1h   (row-major copies into padded rows, one element per thread)
@@ -88,7 +89,12 @@ __global__ void __launch_bounds__(256) k_merge_pack(MhPackAll a)
 #pragma unroll
         for (int i = 0; i < MH_CPT; ++i) {
             const size_t idx = ((size_t)blk * MH_CPT + i) * 256 + threadIdx.x;
-            if (idx < n) { const int r = (int)(idx / Q), q = (int)(idx - (size_t)r * Q); dst[(size_t)r * ldd + q] = (mh16)(src[idx] * sc); }
+            if (idx < n) {
+                const int r = (int)(idx / Q), q = (int)(idx - (size_t)r * Q);
+                const mh16 hv = (mh16)(src[idx] * sc);
+                dst[(size_t)r * ldd + q] = hv;
+                if (job == 0) orn_flag_nonfinite(a.sc, (float)hv);      // every element of G passes here once
+            }
         }
         return;
     }
@@ -239,12 +245,13 @@ size_t orn_merge_h16_host_bytes() { return sizeof(OrnMergeH16); }
 
 // bufs[i]: the layer's half workspace (orn_merge_h16_layer_halfs), zero-filled once by the caller and never cleared
 // again (the padding must stay zero).  host: caller-owned storage of orn_merge_h16_host_bytes().
-int orn_merge_h16_build(void *dev_tables, void *host, int n_layers, const OrnMergeLayer *L, void *const *bufs)
+int orn_merge_h16_build(void *dev_tables, void *host, int n_layers, const OrnMergeLayer *L, void *const *bufs, OrnScaleState *sc)
 {
     ORN_REQUIRE(2 * n_layers <= MH_MAXP && n_layers <= ORN_MAX_LAYERS, "merge h16: too many layers");
     OrnMergeH16 *H = new (host) OrnMergeH16();
     MhGroup *G = new MhGroup[2]();
     H->pack.n = n_layers;
+    H->pack.sc = sc;
     H->pack.blk_start[0] = 0;
     for (int i = 0; i < n_layers; ++i) {
         const OrnMergeLayer &l = L[i];

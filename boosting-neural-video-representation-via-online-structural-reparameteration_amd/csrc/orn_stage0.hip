@@ -38,6 +38,7 @@ struct Stage0P {
     const float *dxn;    // [nslab][H*s*W*s][Cp] gradient wrt the block output, times 1/inv_gs
     int nslab;
     float inv_gs;
+    const OrnScaleState *sc;   // optional: 1/scale from the device-side loss-scale state
     float *dwf, *dbf;    // [O][C][3][3], [O]
     float *dx_slabs;     // [gridDim.x][C][H*W]
 };
@@ -169,6 +170,7 @@ __global__ void __launch_bounds__(1024) k_stage0_bwd(Stage0P p)
     const int s = p.s, ss = s * s, Cn = p.O / ss;
     const int g = blockIdx.x / ss, sub = blockIdx.x - g * ss, si = sub / s, sj = sub - si * s;
     const int n0 = g * 16;                                            // rows r -> channel n0 + r, conv channel (n0 + r)*ss + sub
+    const float inv_gs = p.sc ? p.sc->inv_gs : p.inv_gs;
     S0_STAMP(8);
     {
         float vx[S0_UX], vw[S0_UW];
@@ -210,7 +212,7 @@ __global__ void __launch_bounds__(1024) k_stage0_bwd(Stage0P p)
                 const int e = base + t + k * nt;
                 if (e < 16 * HW) {
                     const int px = e >> 4, r16 = e & 15, h = s0_div(px, p.mW), w = px - h * W;
-                    dys[r16 * XP + (h + 1) * XW + w + 1] = ok[k] ? gsum[k] * p.inv_gs * orn_silu_grad_exact(zz[k]) : 0.f;
+                    dys[r16 * XP + (h + 1) * XW + w + 1] = ok[k] ? gsum[k] * inv_gs * orn_silu_grad_exact(zz[k]) : 0.f;
                 }
             }
         }
@@ -361,12 +363,12 @@ int orn_launch_stage0_fwd(const float *x, const float *wf, const float *bf, int 
 // slabs: orn_stage0_slabs(O, s) * C*H*W floats of scratch; dx [C][H][W] (null: leave the slabs to the caller), dwf, dbf
 // are overwritten.
 int orn_launch_stage0_bwd(const float *x, const float *wf, const float *z, const float *dxn, int nslab, int Cp, float inv_gs, int C,
-                          int O, int H, int W, int s, float *slabs, float *dx, float *dwf, float *dbf, hipStream_t st)
+                          int O, int H, int W, int s, float *slabs, float *dx, float *dwf, float *dbf, hipStream_t st, const OrnScaleState *sc)
 {
     Stage0P p;
     ORN_TRY(fill(p, x, wf, nullptr, C, O, H, W, s));
     ORN_REQUIRE(z && dxn && nslab >= 1 && slabs && dwf && dbf, "stage0_bwd: null pointer");
-    p.z = const_cast<float *>(z); p.dxn = dxn; p.nslab = nslab; p.Cp = Cp; p.inv_gs = inv_gs; p.dwf = dwf; p.dbf = dbf; p.dx_slabs = slabs;
+    p.z = const_cast<float *>(z); p.dxn = dxn; p.nslab = nslab; p.Cp = Cp; p.inv_gs = inv_gs; p.sc = sc; p.dwf = dwf; p.dbf = dbf; p.dx_slabs = slabs;
     const size_t smem = smem_bytes(p.C16, H, W, true);
     ORN_TRY(set_smem(k_stage0_bwd, smem));
     const int nwg = orn_stage0_slabs(O, s);

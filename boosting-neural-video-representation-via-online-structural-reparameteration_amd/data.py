@@ -5,9 +5,42 @@ import math
 import torch
 
 
-def synthetic_video(frames: int, h: int, w: int, seed: int = 1234, device='cuda', noise: float = 0.1) -> torch.Tensor:
+TEXTURE_CUTOFF = 20.0      # default band limit of texture_video (tools/psnr_parity.py sweeps it)
+
+
+def texture_video(frames: int, h: int, w: int, seed: int = 1234, device='cuda', cutoff: float = None) -> torch.Tensor:
+    """[frames,3,h,w] fp32 in [0,1], no white noise: three low-pass-filtered random fields (Gaussian spectrum, `cutoff` cycles per
+    image height at 1 sigma) that drift across the frame at different integer velocities, under a slow brightness wave.
+    Content a NeRV fits to 30-45 dB -- well above any noise floor and far below the resolution where the last bits of the
+    arithmetic decide -- which is what a precision-parity run needs.  Deterministic per seed."""
+    cutoff = TEXTURE_CUTOFF if cutoff is None else cutoff
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    H2, W2 = h + 2 * frames + 8, w + 2 * frames + 8                 # room for the drift
+    fy = torch.fft.fftfreq(H2).view(H2, 1) * H2 * (h / H2)          # cycles per image height
+    fx = torch.fft.rfftfreq(W2).view(1, W2 // 2 + 1) * W2 * (h / W2)
+    env = torch.exp(-(fy ** 2 + fx ** 2) / (2 * cutoff ** 2))
+    out = torch.empty(frames, 3, h, w, device=device)
+    vel = [(1, 2), (2, -1), (-1, 1)]
+    for c in range(3):
+        spec = torch.complex(torch.randn(H2, W2 // 2 + 1, generator=g), torch.randn(H2, W2 // 2 + 1, generator=g)) * env
+        tex = torch.fft.irfft2(spec, s=(H2, W2))
+        tex = ((tex - tex.mean()) / tex.std()).to(device)
+        vy, vx = vel[c]
+        for k in range(frames):
+            oy, ox = frames + 4 + vy * k // 2, frames + 4 + vx * k // 2
+            out[k, c] = tex[oy:oy + h, ox:ox + w]
+    ks = (torch.arange(frames, dtype=torch.float32, device=device) / max(frames, 1)).view(frames, 1, 1, 1)
+    ph = torch.rand(3, generator=g).view(1, 3, 1, 1).to(device)
+    out = 0.5 + 0.17 * out + 0.04 * torch.sin(2 * math.pi * (ks + ph))
+    return out.clamp_(0, 1).contiguous()
+
+
+def synthetic_video(frames: int, h: int, w: int, seed: int = 1234, device='cuda', noise: float = 0.1, kind: str = 'waves') -> torch.Tensor:
     """[frames,3,h,w] fp32 in [0,1]: V[k] = clip(0.5 + sum_4 (0.25/4) sin(2pi(fx x + fy y + k/frames + ph))
-    + noise*U(-1,1)) with 4 random (fx, fy, ph) per channel (SURVEY 8d recipe).  Deterministic per seed."""
+    + noise*U(-1,1)) with 4 random (fx, fy, ph) per channel (SURVEY 8d recipe).  Deterministic per seed.
+    kind='texture': texture_video (drifting band-limited textures, no white noise)."""
+    if kind == 'texture':
+        return texture_video(frames, h, w, seed=seed, device=device)
     g = torch.Generator(device='cpu').manual_seed(seed)
     ys = torch.linspace(0, 1, h, device=device).view(1, 1, h, 1)
     xs = torch.linspace(0, 1, w, device=device).view(1, 1, 1, w)

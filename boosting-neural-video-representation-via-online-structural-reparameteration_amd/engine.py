@@ -196,21 +196,36 @@ class TrainEngine:
         check(lib().orn_engine_set_grad_mask(self._h, _lib.ptr(gm)), 'orn_engine_set_grad_mask')
 
     def profile_step(self):
-        """One eager optimiser step with HIP events around every layer's forward conv launch, on the engine's stream:
-        returns the per-layer kernel durations in ms (host list).  Consumes one schedule entry; synchronises."""
+        """One eager optimiser step with HIP events around the conv launches, on the engine's stream.  Returns a dict of
+        host lists / floats in ms: 'fwd'[i] forward conv of layer i, 'dgrad'[i] dgrad launch of layer i (fp32 mode: the
+        layer's whole backward call), 'wgrad' the batched wgrad launch of the 16-bit layers, 'wgrad_reduce' its split-K
+        reduction.  Consumes one schedule entry; synchronises."""
         if self.frames is None or self.sched is None:
             raise OrnError('set_video() and set_schedule() first')
         import ctypes
         cur = torch.cuda.current_stream()
         self.stream.wait_stream(cur)
         n = self.desc.n_layers
-        ms = (ctypes.c_float * n)()
+        ms = (ctypes.c_float * (2 * n + 2))()
         check(lib().orn_engine_profile_step(self._h, _lib.ptr(self.frames), _lib.ptr(self.embeds), _lib.ptr(self.sched),
                                             _lib.ptr(self.cursor), _lib.ptr(self.stats_ring), c_int32(self.n_slots), ms,
                                             c_void_p(self.stream.cuda_stream)), 'orn_engine_profile_step')
         cur.wait_stream(self.stream)
         self.global_step += 1
-        return [float(x) for x in ms]
+        v = [float(x) for x in ms]
+        return {'fwd': v[:n], 'dgrad': v[n:2 * n], 'wgrad': v[2 * n], 'wgrad_reduce': v[2 * n + 1]}
+
+    def scale_state(self) -> dict:
+        """Dynamic loss scale / non-finite guard of the engine (device state; synchronises): scale, ceiling, flag, steps
+        skipped so far, clean steps since the last change, halvings."""
+        out = (ctypes.c_float * 8)()
+        check(lib().orn_engine_scale_state(self._h, out), 'orn_engine_scale_state')
+        return {'scale': float(out[0]), 'ceiling': float(out[2]), 'flag': int(out[3]), 'skipped': int(out[4]),
+                'good': int(out[5]), 'backoffs': int(out[6])}
+
+    def set_grad_scale(self, scale: float, ceiling: float = 0.0):
+        """Override the live gradient scale of the 16-bit modes (and its ceiling if > 0)."""
+        check(lib().orn_engine_set_grad_scale(self._h, ctypes.c_float(scale), ctypes.c_float(ceiling)), 'orn_engine_set_grad_scale')
 
     def stats(self, n: int) -> torch.Tensor:
         """[n,8] host tensor of the last run's first n steps: loss, L1, MSE, SSIM, PSNR, lr, frame, step."""

@@ -29,7 +29,10 @@
 extern "C" {
 #endif
 
-#define ORN_VERSION 100          /* 0.1.0 */
+#define ORN_VERSION 110          /* 0.1.1 */
+/* Every entry point below is exported with default visibility; the library is built with -fvisibility=hidden, so these (and
+ * the probe-only ones of orn_debug.h) are its whole dynamic symbol table. */
+#define ORN_API __attribute__((visibility("default")))
 #define ORN_MAX_LAYERS 8
 
 #define ORN_OK 0
@@ -37,34 +40,34 @@ extern "C" {
 #define ORN_E_WS (-2)            /* workspace too small */
 #define ORN_E_STATE (-3)         /* engine used in the wrong state */
 
-int orn_version(void);
+ORN_API int orn_version(void);
 /* Copies the last error text of the calling thread into buf (NUL-terminated); returns its length. */
-int orn_last_error(char *buf, size_t n);
+ORN_API int orn_last_error(char *buf, size_t n);
 
 /* ---- A1  PositionalEncoding.forward                                   utils.py:121-129 ------
  * out[b, 2i] = sin(arg), out[b, 2i+1] = cos(arg), arg = fp32(fp32(pos[b]*fp32(lbase^i))*fp32(pi)).
  * lbase_pow[i] = (float)(lbase**i) is computed by the caller in double (Python `lbase ** i`). */
-int orn_pe_fwd(const float *pos, int B, const float *lbase_pow, int levels, float *out, void *stream);
+ORN_API int orn_pe_fwd(const float *pos, int B, const float *lbase_pow, int levels, float *out, void *stream);
 
 /* ---- A2  MLP stem (Linear+SiLU, Linear+SiLU)                         model.py:174-188,612 ----
  * pre1/h1: [B,Hd], pre2/h2: [B,Nout] (h2 is the block input viewed [B,C,fc_h,fc_w]). */
-int orn_stem_fwd(const float *embed, const float *w0, const float *b0, const float *w1, const float *b1,
+ORN_API int orn_stem_fwd(const float *embed, const float *w0, const float *b0, const float *w1, const float *b1,
                  int B, int E, int Hd, int Nout, float *pre1, float *h1, float *pre2, float *h2,
                  void *stream);
 /* dh2 [B,Nout] -> dw0,db0,dw1,db1 (overwritten).  ws: B*(Nout + 258*Hd) floats. */
-int orn_stem_bwd(const float *embed, const float *w1, const float *pre1, const float *h1, const float *pre2,
+ORN_API int orn_stem_bwd(const float *embed, const float *w1, const float *pre1, const float *h1, const float *pre2,
                  const float *dh2, int B, int E, int Hd, int Nout, float *dw0, float *db0, float *dw1,
                  float *db1, float *ws, void *stream);
 
 /* ---- A3  NeRVBlock.get_equivalent_kernel_bias (online ERB merge)     model.py:450-516 --------
  * T[O,C,3,3] (kept for the backward), wf[O,C,3,3], bf[O].  Bit-exact against oracle/merge_ref.c:
  * both contractions are single k-ordered fmaf chains. */
-int orn_erb_merge_fwd(const float *w3x3, const float *b3x3, const float *w3x1, const float *b3x1,
+ORN_API int orn_erb_merge_fwd(const float *w3x3, const float *b3x3, const float *w3x1, const float *b3x1,
                       const float *w1x3, const float *b1x3, const float *w1, const float *w2,
                       const float *w3, int C, int O, float *T, float *wf, float *bf, void *stream);
-size_t orn_erb_merge_bwd_ws_bytes(int C, int O);
+ORN_API size_t orn_erb_merge_bwd_ws_bytes(int C, int O);
 /* g = dL/dwf [O,C,3,3], dbf = dL/dbf [O] -> gradients of the 9 branch tensors (overwritten). */
-int orn_erb_merge_bwd(const float *g, const float *dbf, const float *w1, const float *w2, const float *w3,
+ORN_API int orn_erb_merge_bwd(const float *g, const float *dbf, const float *w1, const float *w2, const float *w3,
                       const float *T, int C, int O, float *d3x3, float *db3x3, float *d3x1, float *db3x1,
                       float *d1x3, float *db1x3, float *dw1, float *dw2, float *dw3, void *ws,
                       size_t ws_bytes, void *stream);
@@ -72,11 +75,11 @@ int orn_erb_merge_bwd(const float *g, const float *dbf, const float *w1, const f
 /* ---- A4  NeRVBlock.forward: conv3x3(pad 1)+bias -> PixelShuffle(s) -> SiLU   model.py:539,567 --
  * x [B,C,H,W]; wf [O,C,3,3]; bf [O]; O = Cn*s*s.  z (pre-activation, post-shuffle) and
  * a = SiLU(z): [B,Cn,H*s,W*s].  z may be NULL for inference (decode). */
-int orn_conv3x3_ps_silu_fwd(const float *x, const float *wf, const float *bf, int B, int C, int O, int H,
+ORN_API int orn_conv3x3_ps_silu_fwd(const float *x, const float *wf, const float *bf, int B, int C, int O, int H,
                             int W, int s, float *z, float *a, void *stream);
-size_t orn_conv3x3_ps_silu_bwd_ws_bytes(int B, int C, int O, int H, int W);
+ORN_API size_t orn_conv3x3_ps_silu_bwd_ws_bytes(int B, int C, int O, int H, int W);
 /* da [B,Cn,Hs,Ws] -> dx [B,C,H,W] (NULL to skip), dwf [O,C,3,3], dbf [O] (overwritten). */
-int orn_conv3x3_ps_silu_bwd(const float *x, const float *wf, const float *z, const float *da, int B, int C,
+ORN_API int orn_conv3x3_ps_silu_bwd(const float *x, const float *wf, const float *z, const float *da, int B, int C,
                             int O, int H, int W, int s, float *dx, float *dwf, float *dbf, void *ws,
                             size_t ws_bytes, void *stream);
 
@@ -85,38 +88,47 @@ int orn_conv3x3_ps_silu_bwd(const float *x, const float *wf, const float *z, con
  * staging (DESIGN.md "data layout") lives in `ws`, which the caller must zero-fill once before the
  * first use (the one-pixel borders are never written).  The engine uses the same kernels without the
  * layout conversions. */
-size_t orn_conv3x3_ps_silu_bf16_ws_bytes(int C, int O, int H, int W, int s);
-int orn_conv3x3_ps_silu_fwd_bf16(const float *x, const float *wf, const float *bf, int C, int O, int H, int W,
+ORN_API size_t orn_conv3x3_ps_silu_bf16_ws_bytes(int C, int O, int H, int W, int s);
+ORN_API int orn_conv3x3_ps_silu_fwd_bf16(const float *x, const float *wf, const float *bf, int C, int O, int H, int W,
                                  int s, float *z, float *a, void *ws, size_t ws_bytes, void *stream);
-int orn_conv3x3_ps_silu_bwd_bf16(const float *x, const float *wf, const float *z, const float *da, int C, int O,
+ORN_API int orn_conv3x3_ps_silu_bwd_bf16(const float *x, const float *wf, const float *z, const float *da, int C, int O,
                                  int H, int W, int s, float *dx, float *dwf, float *dbf, void *ws,
                                  size_t ws_bytes, void *stream);
 
 /* The forward conv kernel on the engine's own channels-last bf16 buffers (DESIGN.md "data layout"):
  * xpad [H+2][W+2][C] zero-bordered, wb [9][O'][C], bias_p [O'] (o' = (i*s+j)*Cn + n), z [H*s][W*s][Cn],
  * apad [H*s+2][W*s+2][Cn] or NULL.  This is the dominant kernel bench.py prices against the MFMA roofline. */
-int orn_conv_nhwc_bf16_fwd(const void *xpad, const void *wb, const float *bias_p, int H, int W, int C, int O,
+ORN_API int orn_conv_nhwc_bf16_fwd(const void *xpad, const void *wb, const float *bias_p, int H, int W, int C, int O,
                            int s, void *z, void *apad, void *stream);
-/* the same kernel built for IEEE half (precision 2 of the engine): buffers hold fp16 */
-int orn_conv_nhwc_f16_fwd(const void *xpad, const void *wb, const float *bias_p, int H, int W, int C, int O,
+/* the same kernel built for IEEE half (precision 2 of the engine, the mode bench.py's headline runs in): buffers hold fp16 */
+ORN_API int orn_conv_nhwc_f16_fwd(const void *xpad, const void *wb, const float *bias_p, int H, int W, int C, int O,
                           int s, void *z, void *apad, void *stream);
 
 /* Same for the two backward kernels (dgrad fused with SiLU' + un-shuffle into the previous layer's dypad;
- * wgrad + dbias into PyTorch-layout dwf [O][96][3][3], dbf [O]) and a timing-only ablation switch for
- * tools/probes (flags make results wrong; 0 restores normal operation). */
-int orn_dgrad_nhwc_bf16(const void *dypad, const void *wd, int H, int W, int O, int C, const void *zprev,
+ * wgrad + dbias into PyTorch-layout dwf [O][96][3][3], dbf [O]) (the timing-only ablation switch of
+ * tools/probes lives in orn_debug.h). */
+ORN_API int orn_dgrad_nhwc_bf16(const void *dypad, const void *wd, int H, int W, int O, int C, const void *zprev,
                         void *dyprev, int sp, void *stream);
-size_t orn_wgrad_nhwc_bf16_ws_bytes(int H, int W, int O);
-int orn_wgrad_nhwc_bf16(const void *xpad, const void *dypad, int H, int W, int C, int O, int s, float *slabs,
+ORN_API size_t orn_wgrad_nhwc_bf16_ws_bytes(int H, int W, int O);
+ORN_API int orn_wgrad_nhwc_bf16(const void *xpad, const void *dypad, int H, int W, int C, int O, int s, float *slabs,
                         float *dwf, float *dbf, void *stream);
-void orn_debug_set(int flags);
+/* IEEE-half twins of the two backward kernels and of the fp32-layout block hooks (same arguments, half buffers, same
+ * workspace sizes): every 16-bit kernel the engine's fp16 mode launches can be checked per op against the oracle. */
+ORN_API int orn_dgrad_nhwc_f16(const void *dypad, const void *wd, int H, int W, int O, int C, const void *zprev,
+                       void *dyprev, int sp, void *stream);
+ORN_API int orn_wgrad_nhwc_f16(const void *xpad, const void *dypad, int H, int W, int C, int O, int s, float *slabs,
+                       float *dwf, float *dbf, void *stream);
+ORN_API int orn_conv3x3_ps_silu_fwd_f16(const float *x, const float *wf, const float *bf, int C, int O, int H, int W, int s,
+                                float *z, float *a, void *ws, size_t ws_bytes, void *stream);
+ORN_API int orn_conv3x3_ps_silu_bwd_f16(const float *x, const float *wf, const float *z, const float *da, int C, int O, int H,
+                                int W, int s, float *dx, float *dwf, float *dbf, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- A5  head: 1x1 conv -> (tanh+1)/2 or sigmoid                      model.py:621-622 --------
  * a [B,C,H,W]; w [3,C,1,1]; b [3]; out [B,3,H,W]. */
-int orn_head_fwd(const float *a, const float *w, const float *b, int B, int C, int H, int W, int sigmoid,
+ORN_API int orn_head_fwd(const float *a, const float *w, const float *b, int B, int C, int H, int W, int sigmoid,
                  float *out, void *stream);
-size_t orn_head_bwd_ws_bytes(int B, int C, int H, int W);
-int orn_head_bwd(const float *a, const float *w, const float *out, const float *dout, int B, int C, int H,
+ORN_API size_t orn_head_bwd_ws_bytes(int B, int C, int H, int W);
+ORN_API int orn_head_bwd(const float *a, const float *w, const float *out, const float *dout, int B, int C, int H,
                  int W, int sigmoid, float *da, float *dw, float *db, void *ws, size_t ws_bytes,
                  void *stream);
 
@@ -127,22 +139,22 @@ int orn_head_bwd(const float *a, const float *w, const float *out, const float *
 #define ORN_LOSS_L2 0
 #define ORN_LOSS_L1 1
 #define ORN_LOSS_FUSION6 2
-size_t orn_loss_ws_bytes(int B, int Ch, int H, int W);
-int orn_loss_fwd_bwd(const float *pred, const float *target, int B, int Ch, int H, int W, int loss_type,
+ORN_API size_t orn_loss_ws_bytes(int B, int Ch, int H, int W);
+ORN_API int orn_loss_fwd_bwd(const float *pred, const float *target, int B, int Ch, int H, int W, int loss_type,
                      float loss_scale, float *stats, float *dpred, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- N3  msssim_fn: pytorch_msssim.ms_ssim(pred, target, data_range=1, size_average=True)   utils.py:201-211
  * Logging metric of the reference's train/eval loops (main_train.py:254); synchronises the stream (not for the
  * captured training step).  out: one device float.  min(H, W) must exceed 160. */
-size_t orn_msssim_ws_bytes(int B, int Ch, int H, int W);
-int orn_msssim(const float *pred, const float *target, int B, int Ch, int H, int W, float *out, void *ws,
+ORN_API size_t orn_msssim_ws_bytes(int B, int Ch, int H, int W);
+ORN_API int orn_msssim(const float *pred, const float *target, int B, int Ch, int H, int W, float *out, void *ws,
                size_t ws_bytes, void *stream);
 
 /* ---- A9  optim.Adam.step over one flat arena                          main_train.py:196,250 ---
  * p,g,m,v: n floats each.  step = 1-based global step.  weight decay 0, amsgrad off.
  * Hyper-parameters are doubles (as Python holds them): 1-beta, lr/(1-beta1^t) and sqrt(1-beta2^t)
  * are formed in double and rounded to fp32 once, exactly as torch.optim.Adam does. */
-int orn_adam_step(float *p, const float *g, float *m, float *v, size_t n, double lr, double beta1,
+ORN_API int orn_adam_step(float *p, const float *g, float *m, float *v, size_t n, double lr, double beta1,
                   double beta2, double eps, int step, void *stream);
 
 /* ---- A11  the whole per-frame training step as one engine           main_train.py:229-254 ----
@@ -180,32 +192,43 @@ typedef struct orn_step_sched {
 
 typedef struct orn_engine orn_engine;
 
-size_t orn_engine_ws_bytes(const orn_engine_desc *d);
-int orn_engine_create(const orn_engine_desc *d, float *params, float *grads, float *adam_m, float *adam_v,
+ORN_API size_t orn_engine_ws_bytes(const orn_engine_desc *d);
+ORN_API int orn_engine_create(const orn_engine_desc *d, float *params, float *grads, float *adam_m, float *adam_v,
                       void *ws, size_t ws_bytes, orn_engine **out);
-void orn_engine_destroy(orn_engine *e);
+ORN_API void orn_engine_destroy(orn_engine *e);
 /* Forward only (decode): embed [E] device -> img [3,H,W] device. */
-int orn_engine_decode(orn_engine *e, const float *embed, float *img, void *stream);
+ORN_API int orn_engine_decode(orn_engine *e, const float *embed, float *img, void *stream);
 /* One optimiser step.  frames [n_frames,3,H,W], embeds [n_frames,E] (device); sched: device array,
  * `cursor` a device int32 the step reads and post-increments, so `n` back-to-back steps consume
  * sched[cursor..cursor+n).  stats_out: device [n_slots][8] ring written at slot (cursor % n_slots). */
-int orn_engine_train_step(orn_engine *e, const float *frames, const float *embeds,
+ORN_API int orn_engine_train_step(orn_engine *e, const float *frames, const float *embeds,
                           const orn_step_sched *sched, int32_t *cursor, float *stats_out, int32_t n_slots,
                           void *stream);
 /* Optional 0/1 gradient mask in the arena layout (device, float, 16-byte aligned; null removes it): gradients are
  * multiplied by it before Adam.  The prune fine-tune of main_eval.py:213-531 -- torch.nn.utils.prune keeps
  * weight = weight_orig * mask, so pruned entries never receive a gradient -- and its frozen tensors. */
-int orn_engine_set_grad_mask(orn_engine *e, const float *mask);
-/* One eager training step with HIP events around every layer's forward conv launch (ms_out[n_layers], host);
- * synchronises the stream.  Measurement hook for bench.py's roofline leg -- no reference counterpart. */
-int orn_engine_profile_step(orn_engine *e, const float *frames, const float *embeds, const orn_step_sched *sched,
+ORN_API int orn_engine_set_grad_mask(orn_engine *e, const float *mask);
+/* One eager training step with HIP events around the conv launches, on the launch stream; synchronises it.  ms_out (host,
+ * 2*n_layers + 2 floats): [i] forward conv of layer i, [n_layers + i] dgrad launch of layer i (0: none), [2*n_layers] the
+ * batched wgrad launch of the 16-bit layers, [2*n_layers + 1] its split-K reduction (0 in fp32 mode, where each layer's
+ * backward is one multi-kernel call reported under its dgrad slot).  Measurement hook for bench.py's roofline leg -- no
+ * reference counterpart. */
+ORN_API int orn_engine_profile_step(orn_engine *e, const float *frames, const float *embeds, const orn_step_sched *sched,
                             int32_t *cursor, float *stats_out, int32_t n_slots, float *ms_out, void *stream);
 /* Capture one train step into a hipGraph on `stream` and replay it n times (same arguments as above). */
-int orn_engine_train_steps_graph(orn_engine *e, const float *frames, const float *embeds,
+ORN_API int orn_engine_train_steps_graph(orn_engine *e, const float *frames, const float *embeds,
                                  const orn_step_sched *sched, int32_t *cursor, float *stats_out,
                                  int32_t n_slots, int32_t n_steps, void *stream);
+/* Dynamic loss scale + non-finite guard (the reference trains in fp32 and has neither; torch.cuda.amp.GradScaler is the
+ * model).  The 16-bit gradient tensors of precision 2 travel multiplied by a scale held in device memory (2^20 at creation;
+ * 1 for the other precisions).  A step whose gradients (or loss) are not finite leaves parameters and Adam moments untouched
+ * and halves the scale; 2000 clean steps double it again up to its initial value.  All of it happens on the device, inside
+ * the captured step.  out8 (host): {scale, 1/scale, ceiling, flag, steps skipped, clean steps, halvings, 0}; synchronises. */
+ORN_API int orn_engine_scale_state(orn_engine *e, float *out8);
+/* Overrides the live scale (>= 1) and, if gs_max > 0, its ceiling: tests inject an overflowing step this way. */
+ORN_API int orn_engine_set_grad_scale(orn_engine *e, float gs, float gs_max);
 /* Merged (deploy) kernel/bias of layer i, valid after a decode / train step (model.py:395-448). */
-int orn_engine_fused_kernel(orn_engine *e, int layer, const float **wf, const float **bf);
+ORN_API int orn_engine_fused_kernel(orn_engine *e, int layer, const float **wf, const float **bf);
 
 #ifdef __cplusplus
 }

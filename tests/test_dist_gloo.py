@@ -60,3 +60,29 @@ def test_shard_videos_single_process():
     assert seen == list(range(7)) and du.shard_videos(7, 8, 7) == []
     assert du.max_over_ranks(None, 3.5) == 3.5
     assert du.gather_records(None, [1, 2, 3, 4, 5]) == [[1.0, 2.0, 3.0, 4.0, 5.0]]
+
+
+def test_bench_self_launch_two_ranks_gloo():
+    """`python bench.py --gpus 2` with no outer launcher: the parent spawns two fresh rank processes before touching any GPU,
+    they rendezvous (gloo here, RCCL on the GPU box), time the steps between barriers, reduce MAX over ranks, and rank 0
+    prints the one JSON line with the rank count of the process group and the per-rank rates.  --cpu-stub replaces the
+    engine by a sleep so the launcher / reduction path runs on a machine without a GPU."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--cpu-stub', '--steps', '6',
+                          '--warmup', '2'], capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS='1'))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['rccl_ranks'] == 2 and len(d['per_rank_frames_per_s']) == 2
+    assert d['steps'] == 6 and d['warmup'] == 2 and d['scaling'] == 'weak' and d['value'] > 0
+    # whole-job aggregate = ranks * steps / max-over-ranks time
+    assert abs(d['value'] - 2 * 6 / (d['ms_per_step'] * 6 / 1e3)) < 1e-6 * d['value']
+
+
+def test_bench_self_launch_reports_a_failing_rank():
+    """A rank that dies makes the launcher exit non-zero (WORLD_SIZE mismatch injected through --gpus vs a bad env)."""
+    env = dict(os.environ, ORN_BENCH_FAIL_RANK='1')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--cpu-stub', '--steps', '2',
+                          '--warmup', '1'], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0

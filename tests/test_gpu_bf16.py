@@ -19,18 +19,24 @@ def orn():
     return orn_amd
 
 
-def _bf16_round(t):
-    return t.to(torch.bfloat16).to(torch.float32)
+def _half_round(t, half):
+    return t.to(torch.bfloat16 if half == 'bf16' else torch.float16).to(torch.float32)
 
 
+@pytest.mark.parametrize('half', ['bf16', 'fp16'])
 @pytest.mark.parametrize('C,O,H,W,s', [(96, 384, 8, 32, 2), (96, 384, 36, 64, 2), (96, 384, 45, 80, 2), (96, 384, 13, 37, 2),
                                        (96, 1152, 9, 33, 3)])
-def test_bf16_block_fwd_bwd(orn, C, O, H, W, s):
-    """conv3x3+PixelShuffle+SiLU fwd, and dbias / wgrad / dgrad, on bf16 MFMA vs the CPU oracle run on
-    the SAME bf16-rounded inputs (isolates kernel correctness from input quantisation):
-    exact integer-free check would hide layout bugs, so data are asymmetric random."""
+def test_bf16_block_fwd_bwd(orn, C, O, H, W, s, half):
+    """conv3x3+PixelShuffle+SiLU fwd, and dbias / wgrad / dgrad, on 16-bit MFMA -- the bf16 build AND the IEEE-half build
+    the engine's fp16 mode (bench.py's headline) launches -- vs the CPU oracle run on the SAME 16-bit-rounded inputs
+    (isolates kernel correctness from input quantisation): exact integer-free check would hide layout bugs, so data are
+    asymmetric random.  Tolerances: outputs are stored in 16 bit (2^-9 bf16 / 2^-12 fp16 relative) on fp32 accumulation."""
     from oracle import cpu_ref
     L, P, st = orn._lib.lib(), orn._lib.ptr, orn._lib.stream
+    _bf16_round = lambda t: _half_round(t, half)
+    fwd_fn = L.orn_conv3x3_ps_silu_fwd_bf16 if half == 'bf16' else L.orn_conv3x3_ps_silu_fwd_f16
+    bwd_fn = L.orn_conv3x3_ps_silu_bwd_bf16 if half == 'bf16' else L.orn_conv3x3_ps_silu_bwd_f16
+    tol = 5e-3 if half == 'bf16' else 1e-3
     gen = torch.Generator().manual_seed(C + O + H * W)
     x = _bf16_round(torch.randn(1, C, H, W, generator=gen))
     wf = _bf16_round(torch.randn(O, C, 3, 3, generator=gen) / math.sqrt(9 * C))
@@ -47,10 +53,9 @@ def test_bf16_block_fwd_bwd(orn, C, O, H, W, s):
     xd, wd, bd = x.cuda(), wf.cuda(), bf.cuda()
     z = torch.empty(1, Cn, H * s, W * s, device='cuda')
     a = torch.empty_like(z)
-    orn._lib.check(L.orn_conv3x3_ps_silu_fwd_bf16(P(xd), P(wd), P(bd), C, O, H, W, s, P(z), P(a), P(ws), c_size_t(nb), st()))
-    # outputs are stored as bf16: 2^-9 relative rounding on top of fp32 accumulation
-    np.testing.assert_allclose(z.cpu().numpy(), zr.detach().numpy(), rtol=5e-3, atol=5e-3)
-    np.testing.assert_allclose(a.cpu().numpy(), ar.detach().numpy(), rtol=5e-3, atol=5e-3)
+    orn._lib.check(fwd_fn(P(xd), P(wd), P(bd), C, O, H, W, s, P(z), P(a), P(ws), c_size_t(nb), st()))
+    np.testing.assert_allclose(z.cpu().numpy(), zr.detach().numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(a.cpu().numpy(), ar.detach().numpy(), rtol=tol, atol=tol)
     if C != 96:
         return
     # backward with the oracle's z and the same bf16-rounded dy the kernel sees
@@ -63,7 +68,7 @@ def test_bf16_block_fwd_bwd(orn, C, O, H, W, s):
     dwf = torch.empty(O, C, 3, 3, device='cuda')
     dbf = torch.empty(O, device='cuda')
     zd, dad = zr.detach().cuda().contiguous(), da.cuda()       # keep alive: ptr() does not hold a reference
-    orn._lib.check(L.orn_conv3x3_ps_silu_bwd_bf16(P(xd), P(wd), P(zd), P(dad), C, O, H, W, s,
+    orn._lib.check(bwd_fn(P(xd), P(wd), P(zd), P(dad), C, O, H, W, s,
                                                   P(dx), P(dwf), P(dbf), P(ws), c_size_t(nb), st()))
     torch.cuda.synchronize()
     sc = float(gw.abs().max())
@@ -126,9 +131,9 @@ def test_bf16_engine_720p_decode_and_step(orn, half, cfg):
     and gradients close to fp32."""
     import bench
     outs = {}
-    kw = dict(fc_hw_dim='9_16_48', strides=[5, 3, 2, 2, 2], hw=(1080, 1920), frames=8) if cfg == '1080p' else {}
+    kw = dict(frames=8) if cfg == '1080p' else {}
     for prec in ('fp32', half):
-        eng = bench.make_engine(seed=1234, precision=prec, **kw)
+        eng = bench.make_engine(seed=1234, precision=prec, cfg=bench.CONFIGS[cfg], **kw)
         eng.set_schedule([(7, 1, 0.0)])
         eng.run(1, graph=True)
         torch.cuda.synchronize()
@@ -193,7 +198,8 @@ def test_profile_step_and_grad_mask(orn):
     assert torch.equal(after[frozen], before[frozen]) and not torch.equal(after[~frozen], before[~frozen])
     eng.set_grad_mask(None)
     ms = eng.profile_step()
-    assert len(ms) == 3 and all(0.0 < m < 5.0 for m in ms), ms
+    assert len(ms['fwd']) == 3 and all(0.0 < m < 5.0 for m in ms['fwd']), ms
+    assert all(0.0 < m < 5.0 for m in ms['dgrad']) and 0.0 < ms['wgrad'] < 5.0 and 0.0 < ms['wgrad_reduce'] < 5.0, ms
     eng.run(1, graph=True)
     torch.cuda.synchronize()
     assert not torch.equal(eng.params[off:off + n][frozen], before[frozen])

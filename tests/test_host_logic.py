@@ -27,7 +27,13 @@ def test_library_exports_every_declared_symbol(orn):
     assert declared == set(orn._lib.EXPORTS), declared ^ set(orn._lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name)
-    assert L.orn_version() == 100
+    assert L.orn_version() == 110
+    # ... and nothing else: the dynamic symbol table is the C ABI (orn.h + the probe-only orn_debug.h), no kernel stubs
+    import subprocess
+    dbg = set(re.findall(r'\b(orn_[a-z0-9_]+)\s*\(', open(os.path.join(ROOT, 'include', 'orn_debug.h')).read()))
+    out = subprocess.run(['nm', '-D', '--defined-only', orn._lib.lib_path()], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert declared <= exported and exported <= declared | dbg, exported ^ declared
     # argument errors come back as codes + text, not exceptions across the ABI (no GPU needed)
     assert L.orn_pe_fwd(None, 0, None, 0, None, None) == -1
     assert 'pe_fwd' in orn._lib.last_error()

@@ -10,13 +10,13 @@ res = {l: [] for l in libs}
 for r in range(rounds):
     for l in libs:
         env = dict(os.environ, ORN_LIB_PATH=os.path.abspath(l))
-        out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--no-cpu-baseline', '--steps', steps, '--warmup', '66'], env=env,
+        out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--no-cpu-baseline', '--no-fp32', '--steps', steps, '--warmup', '66'], env=env,
                              capture_output=True, text=True)
         try:
             d = json.loads(out.stdout.strip().splitlines()[-1])
             res[l].append(d['ms_per_step'])
-            print(f'round {r} {os.path.basename(l)}: {d["ms_per_step"]:.4f} ms/step  ({d["value"]:.1f} f/s)  per-layer fwd us: '
-                  + ' '.join(f'{x["ms"]*1e3:.1f}' for x in d['roofline']['per_layer']), flush=True)
+            print(f'round {r} {os.path.basename(l)}: {d["ms_per_step"]:.4f} ms/step  ({d["value"]:.1f} f/s)  conv us: '
+                  + ' | '.join(f'{x["kernel"].split("::")[-1][:34]} {x["us_per_step"]:.1f}' for x in d['roofline']['kernels']), flush=True)
         except Exception as e:
             print('FAILED', l, out.stdout[-500:], out.stderr[-1500:], flush=True)
 for l in libs:
