@@ -104,9 +104,9 @@ def first_fast_layer(geo, precision):
     if precision == 'fp32':
         return len(geo)
     ff = len(geo)
-    while ff > 0 and geo[ff - 1]['C'] == 96 and geo[ff - 1]['O'] % 128 == 0:
+    while ff > 0 and geo[ff - 1]['C'] == 96 and geo[ff - 1]['O'] % 96 == 0:
         ff -= 1
-    if 0 < ff < len(geo) and geo[ff - 1]['C'] < 96 and geo[ff - 1]['O'] % 128 == 0:
+    if 0 < ff < len(geo) and geo[ff - 1]['C'] < 96 and geo[ff - 1]['O'] % 96 == 0:
         ff -= 1
     return ff
 

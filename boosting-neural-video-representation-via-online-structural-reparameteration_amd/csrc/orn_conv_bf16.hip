@@ -58,7 +58,7 @@ static int g_conv_dbg = 0;   // timing experiments only (tools/probes), see orn_
 #ifdef ORN_CONV_STAMP
 static unsigned long long *g_conv_stamps = nullptr;
 // stamps collect in 512 B of LDS behind the kernel's own images (a global store per stamp would sit in every vmcnt wait)
-#define STAMP_LDS ((unsigned long long *)(smem + PATCH_LDS + NBUF * BS_BYTES + (EPI_IS_FWD(EPI) ? ((p.Nout * 4 + 255) & ~255) : 0)))
+#define STAMP_LDS ((unsigned long long *)(smem + PATCH_LDS + NBUF * BS_BYTES + (EPI_IS_FWD(EPI) ? ((((p.Nout + BN - 1) / BN * BN) * 4 + 255) & ~255) : 0)))
 #define STAMP(i_) { if (p.stamps && t == 0) STAMP_LDS[i_] = __builtin_amdgcn_s_memtime(); }
 #define STAMP_RT(i_) { if (p.stamps && t == 0) STAMP_LDS[i_] = __builtin_amdgcn_s_memrealtime(); }
 #define STAMP_FLUSH() { if (p.stamps && t < 128) p.stamps[(size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 128 + t] = STAMP_LDS[t]; }
@@ -313,7 +313,8 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
     const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.apad, 0, APAD ? p.apad_bytes : 0, 0x00020000);
     float *sbias = reinterpret_cast<float *>(smem + PATCH_LDS + NBUF * BS_BYTES);     // [Nout] after the weight ring (EPI_B_FWD)
     if (EPI_IS_FWD(EPI))
-        for (int i = t; i < p.Nout; i += NT) sbias[i] = p.bias ? p.bias[i] : 0.f;   // visible after the first N tile's barriers
+        for (int i = t; i < (p.Nout + BN - 1) / BN * BN; i += NT)                    // visible after the first N tile's barriers
+            sbias[i] = (p.bias && i < p.Nout) ? p.bias[i] : 0.f;                    // (zeros behind Nout: a ragged last N tile)
 #ifdef ORN_CONV_PRIO
     if (NLOAD != NWAVES && uwave >= NLOAD) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for the non-loader half
 #endif
@@ -454,15 +455,18 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
                         const int ij = conv_div(c8, p.mCn), n = c8 - ij * p.Cn;
                         const int si = conv_div(ij, p.mS), sj = ij - si * p.s;
                         const int Ws = W * p.s, oh = gh * p.s + si, ow = gw * p.s + sj;
+                        // (a ragged last N tile -- Nout not a multiple of the N tile -- computes its missing 32-channel blocks
+                        // on whatever weight rows follow in memory and drops them here)
+                        const bool okc = ok && c8 < p.Nout;
                         __builtin_amdgcn_raw_buffer_store_b128(u32x4{za0, za1, zb0, zb1}, z_rsrc,
-                                                               ok ? ((oh * Ws + ow) * p.Cn + n) * 2 : (int)0x80000000, 0, 0);   // < 2^31 bytes: launcher
+                                                               okc ? ((oh * Ws + ow) * p.Cn + n) * 2 : (int)0x80000000, 0, 0);   // < 2^31 bytes: launcher
                         if (APAD) {
                             unsigned aa0 = pack_h16x2(orn_silu(va[0]), orn_silu(va[1])), aa1 = pack_h16x2(orn_silu(va[2]), orn_silu(va[3]));
                             unsigned ab0 = pack_h16x2(orn_silu(vb[0]), orn_silu(vb[1])), ab1 = pack_h16x2(orn_silu(vb[2]), orn_silu(vb[3]));
                             swap_halves(aa0, ab0); swap_halves(aa1, ab1);
                             // the activation copy leaves right away (the next vmcnt wait is a whole tap of the next N tile away)
                             __builtin_amdgcn_raw_buffer_store_b128(u32x4{aa0, aa1, ab0, ab1}, a_rsrc,
-                                                                   ok ? (((oh + 1) * (Ws + 2) + (ow + 1)) * p.Cn + n) * 2 : (int)0x80000000, 0, 0);
+                                                                   okc ? (((oh + 1) * (Ws + 2) + (ow + 1)) * p.Cn + n) * 2 : (int)0x80000000, 0, 0);
                         }
                     } else {
                         float v[8];
@@ -512,7 +516,7 @@ static int launch_conv_cfg(const ConvBP &p, int n_tiles_total, hipStream_t st)
     constexpr int BN = WAVES_N * NB * 32;
     constexpr int NT = WAVES_M * WAVES_N * 64;
     constexpr size_t LDS_IMG = (size_t)(CB_PH * CB_PW * CK * 2 + 1023) / 1024 * 1024 + (ALLTAPS ? 9 : 3) * (size_t)BN * CK * 2;
-    size_t smem = LDS_IMG + (EPI_IS_FWD(EPI) ? orn_align((size_t)p.Nout * 4) : 0);   // + bias copy
+    size_t smem = LDS_IMG + (EPI_IS_FWD(EPI) ? orn_align((size_t)orn_cdiv(p.Nout, BN) * BN * 4) : 0);   // + bias copy (whole N tiles)
 #ifdef ORN_CONV_STAMP
     smem += 1024;
 #endif
@@ -554,7 +558,10 @@ static unsigned conv_magic(int d)
 int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p, int H, int W, int Cin, int O, int s,
                              h16 *z, h16 *apad, hipStream_t st, int c_real)
 {
-    ORN_REQUIRE(Cin % CB_CK == 0 && O % 128 == 0 && O % (s * s) == 0, "conv_bf16_fwd: unsupported Cin=%d O=%d s=%d", Cin, O, s);
+    // O % 32: whole MFMA blocks; an O that is not a multiple of the 128-channel N tile gets a ragged last tile whose weight
+    // DMA reads up to 96 rows past row O of each tap: `wb` must be readable for 96 * Cin elements behind its last row
+    // (orn_conv_bf16_wb_elems; the values are never used)
+    ORN_REQUIRE(Cin % CB_CK == 0 && O % 32 == 0 && O % (s * s) == 0, "conv_bf16_fwd: unsupported Cin=%d O=%d s=%d", Cin, O, s);
     ConvBP p = {};
     p.dbg = g_conv_dbg;
 #ifdef ORN_CONV_STAMP
@@ -567,7 +574,7 @@ int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p
     p.z_bytes = (unsigned)((size_t)(H * s) * (W * s) * p.Cn * 2);
     p.apad_bytes = apad ? (unsigned)((size_t)(H * s + 2) * (W * s + 2) * p.Cn * 2) : 0;
     p.mCn = conv_magic(p.Cn); p.mS = conv_magic(s);
-    const int nt_total = O / 128;
+    const int nt_total = orn_cdiv(O, 128);
     // One work-group per CU (LDS): keep a pixel tile's N tiles together (patch staged once) unless cutting them
     // apart fills the chip better.  Cost model in units of one N tile: rounds x (work + ~0.3 for the patch).
     const int ptiles = p.tiles_w * p.tiles_h;
@@ -798,6 +805,7 @@ __device__ __forceinline__ void wgrad_body(const WgradBP &p, const int id)
 #undef WDMA16
 #undef WDMA_TILE
     bsum += __shfl_xor(bsum, 32);                             // the two K halves of the row
+    if (o0 + wave * 32 >= O) return;                          // ragged last tile (O % 128 != 0): this wave's 32 channels do not exist
     if (do_bias && hh == 0) p.bias_slabs[(size_t)sidx * O + o0 + wave * 32 + l31] = bsum;
     float *out = p.slabs + (size_t)sidx * 9 * O * 96;
 #pragma unroll
@@ -923,7 +931,7 @@ int orn_wgrad_bf16_split(int H, int W, int O)
     // S slabs of 9*O*96 floats are written and re-read: keep >= 8 K tiles per work-group so the slab traffic
     // stays small next to the layer's own data, up to one full wave of work-groups (2 per CU)
     const int n_ktiles = orn_cdiv(H, WB_TH) * orn_cdiv(W, WB_TW);
-    const int per = 3 * (O / WB_BO);
+    const int per = 3 * orn_cdiv(O, WB_BO);
     int S = (512 / per) / 8 * 8;
     // measured at the 720p shapes: below ~2000 K tiles a full wave of work-groups makes the slab write + re-read cost
     // more than the idle CUs do (L3, 900 tiles: 40 slabs beat 56 by 17 us per step)
@@ -940,14 +948,16 @@ size_t orn_wgrad_bf16_ws_floats(int H, int W, int O) { return (size_t)orn_wgrad_
 // channels per pixel (zeros above C).
 static int wgrad_fill(WgradBP &p, const h16 *xpad, const h16 *dypad, int H, int W, int C, int O, int s, float *slabs)
 {
-    ORN_REQUIRE(C >= 1 && C <= 96 && O % WB_BO == 0 && O % (s * s) == 0, "wgrad_bf16: unsupported C=%d O=%d", C, O);
+    // O % 32: a ragged last 128-channel tile reads up to 96 channels past the last pixel's: dypad must be readable for 96
+    // elements behind its end (the engine and the per-op hooks pad it)
+    ORN_REQUIRE(C >= 1 && C <= 96 && O % 32 == 0 && O % (s * s) == 0, "wgrad_bf16: unsupported C=%d O=%d", C, O);
     p.dbg = g_conv_dbg;
     p.xpad = xpad; p.dypad = dypad; p.slabs = slabs; p.H = H; p.W = W; p.O = O;
     p.tiles_w = orn_cdiv(W, WB_TW);
     p.n_ktiles = p.tiles_w * orn_cdiv(H, WB_TH);
     p.S = orn_wgrad_bf16_split(H, W, O);
     p.bias_slabs = slabs + (size_t)p.S * 9 * O * 96;
-    p.n_otiles = O / WB_BO;
+    p.n_otiles = orn_cdiv(O, WB_BO);
     static bool attr_done = false;
     if (!attr_done) {
         const size_t smem = 2 * WB_BUF_BYTES;
@@ -1511,11 +1521,11 @@ extern "C" size_t orn_conv3x3_ps_silu_bf16_ws_bytes(int C, int O, int H, int W, 
     const size_t Hs = (size_t)H * s, Ws = (size_t)W * s, Cn = O / (s * s);
     size_t b = 0;
     b += alh((size_t)(H + 2) * (W + 2) * C) * 2;          // xpad
-    b += 2 * alh((size_t)9 * O * C) * 2;                  // wb, wd
+    b += 2 * alh((size_t)9 * O * C + 96 * C) * 2;         // wb, wd (+ the rows a ragged last N tile reads past the end)
     b += orn_align((size_t)O * 4);                        // bias'
     b += alh(Hs * Ws * Cn) * 2;                           // z bf16
     b += alh((Hs + 2) * (Ws + 2) * Cn) * 2;               // apad
-    b += alh((size_t)(H + 2) * (W + 2) * O) * 2;          // dypad
+    b += alh((size_t)(H + 2) * (W + 2) * O + 128) * 2;    // dypad (+ what a ragged last wgrad tile reads past the end)
     b += orn_align(orn_wgrad_bf16_ws_floats(H, W, O) * 4);
     b += orn_align(orn_dbias_bf16_ws_floats(H, O) * 4);
     b += orn_align((size_t)H * W * C * 4 * 8);            // dx fp32 NHWC (up to 8 chunk slabs)
@@ -1534,12 +1544,12 @@ static Bf16Ws carve_bf16(void *ws, int C, int O, int H, int W, int s)
     unsigned char *p = (unsigned char *)ws;
     Bf16Ws r;
     r.xpad = (h16 *)p; p += alh((size_t)(H + 2) * (W + 2) * C) * 2;
-    r.wb = (h16 *)p; p += alh((size_t)9 * O * C) * 2;
-    r.wd = (h16 *)p; p += alh((size_t)9 * O * C) * 2;
+    r.wb = (h16 *)p; p += alh((size_t)9 * O * C + 96 * C) * 2;
+    r.wd = (h16 *)p; p += alh((size_t)9 * O * C + 96 * C) * 2;
     r.biasp = (float *)p; p += orn_align((size_t)O * 4);
     r.zb = (h16 *)p; p += alh(Hs * Ws * Cn) * 2;
     r.apad = (h16 *)p; p += alh((Hs + 2) * (Ws + 2) * Cn) * 2;
-    r.dypad = (h16 *)p; p += alh((size_t)(H + 2) * (W + 2) * O) * 2;
+    r.dypad = (h16 *)p; p += alh((size_t)(H + 2) * (W + 2) * O + 128) * 2;
     r.slabs = (float *)p; p += orn_align(orn_wgrad_bf16_ws_floats(H, W, O) * 4);
     r.dbp = (float *)p; p += orn_align(orn_dbias_bf16_ws_floats(H, O) * 4);
     r.dxn = (float *)p;
@@ -1552,7 +1562,7 @@ extern "C" int HOOK(orn_conv3x3_ps_silu_fwd_bf16, orn_conv3x3_ps_silu_fwd_f16)(c
                                             int s, float *z, float *a, void *ws, size_t ws_bytes, void *stream)
 {
     ORN_REQUIRE(x && wf && bf && a && ws, "conv3x3_ps_silu_fwd_bf16: null pointer");
-    ORN_REQUIRE(C % CB_CK == 0 && O % 128 == 0 && O % (s * s) == 0, "conv3x3_ps_silu_fwd_bf16: unsupported C=%d O=%d s=%d", C, O, s);
+    ORN_REQUIRE(C % CB_CK == 0 && O % 32 == 0 && O % (s * s) == 0, "conv3x3_ps_silu_fwd_bf16: unsupported C=%d O=%d s=%d", C, O, s);
     if (ws_bytes < orn_conv3x3_ps_silu_bf16_ws_bytes(C, O, H, W, s)) { orn_set_error("conv3x3_ps_silu_fwd_bf16: workspace too small"); return ORN_E_WS; }
     hipStream_t st = (hipStream_t)stream;
     const Bf16Ws b = carve_bf16(ws, C, O, H, W, s);
@@ -1572,7 +1582,7 @@ extern "C" int HOOK(orn_conv3x3_ps_silu_bwd_bf16, orn_conv3x3_ps_silu_bwd_f16)(c
                                             size_t ws_bytes, void *stream)
 {
     ORN_REQUIRE(x && wf && z && da && dwf && dbf && ws, "conv3x3_ps_silu_bwd_bf16: null pointer");
-    ORN_REQUIRE(C == 96 && O % 128 == 0 && O % (s * s) == 0, "conv3x3_ps_silu_bwd_bf16: unsupported C=%d O=%d", C, O);
+    ORN_REQUIRE(C == 96 && O % 96 == 0 && O % (s * s) == 0, "conv3x3_ps_silu_bwd_bf16: unsupported C=%d O=%d", C, O);
     if (ws_bytes < orn_conv3x3_ps_silu_bf16_ws_bytes(C, O, H, W, s)) { orn_set_error("conv3x3_ps_silu_bwd_bf16: workspace too small"); return ORN_E_WS; }
     hipStream_t st = (hipStream_t)stream;
     const Bf16Ws b = carve_bf16(ws, C, O, H, W, s);

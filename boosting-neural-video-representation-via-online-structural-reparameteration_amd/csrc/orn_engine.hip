@@ -95,7 +95,8 @@ static int check_desc(const orn_engine_desc *d)
 #define ORN_FAST_C 96          // input channels per pixel of every 16-bit channels-last buffer
 static bool layer_is_fast(const orn_layer_desc &l)
 {
-    return l.C == ORN_FAST_C && l.O % 128 == 0 && l.O % (l.s * l.s) == 0;
+    // O % 96: whole 32-channel MFMA blocks forward (a last N tile of 96 is ragged) and whole 96-channel K chunks in the dgrad
+    return l.C == ORN_FAST_C && l.O % 96 == 0 && l.O % (l.s * l.s) == 0;
 }
 
 // First layer from which every layer (and the head) can run on the bf16 MFMA path.
@@ -111,7 +112,7 @@ static int first_fast_layer(const orn_engine_desc *d)
     // anyway): 3.7x the FLOPs of C=26 on a 16x faster pipe, and none of the fp32 path's small launches
     if (ff > 0 && ff < d->n_layers) {
         const orn_layer_desc &l = d->layer[ff - 1];
-        if (l.C < ORN_FAST_C && l.O % 128 == 0 && l.O % (l.s * l.s) == 0) --ff;
+        if (l.C < ORN_FAST_C && l.O % 96 == 0 && l.O % (l.s * l.s) == 0) --ff;
     }
     return ff;
 }
@@ -149,10 +150,10 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
             if (s0 > s1) s1 = s0;
         } else {
             // halfs are carved as floats (2 per float)
-            const size_t wpz = (size_t)l.O * ORN_FAST_C * 9;
+            const size_t wpz = (size_t)l.O * ORN_FAST_C * 9 + 96 * ORN_FAST_C;      // + the rows a ragged last N tile reads past the end
             L[i].xpad = (uint16_t *)take(((size_t)(l.H + 2) * (l.W + 2) * ORN_FAST_C + 1) / 2);
             L[i].zb = (uint16_t *)take((asz + 1) / 2);
-            L[i].dypad = (uint16_t *)take(((size_t)(l.H + 2) * (l.W + 2) * l.O + 1) / 2);
+            L[i].dypad = (uint16_t *)take(((size_t)(l.H + 2) * (l.W + 2) * l.O + 128 + 1) / 2);   // + a ragged wgrad tile's over-read
             L[i].wb = (uint16_t *)take((wpz + 1) / 2);
             L[i].wd = (uint16_t *)take((wpz + 1) / 2);
             L[i].biasp = take(l.O);

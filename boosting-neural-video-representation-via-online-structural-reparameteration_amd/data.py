@@ -58,24 +58,53 @@ def synthetic_video(frames: int, h: int, w: int, seed: int = 1234, device='cuda'
     return v.clamp_(0, 1).contiguous()
 
 
-def load_png_dir(main_dir: str, vid_list=(None,), frame_gap: int = 1, device='cuda') -> torch.Tensor:
-    """CustomDataSet (model.py:11-70) without DataLoader workers: every `frame_gap`-th PNG of `main_dir`
-    (optionally filtered by video id prefix), ToTensor semantics (uint8/255 -> fp32 CHW), portrait frames
-    transposed to landscape (model.py:66-67), uploaded once and kept resident in HBM."""
-    import os
-    import numpy as np
-    from PIL import Image
-    names = sorted(f for f in os.listdir(main_dir) if f.lower().endswith(('.png', '.jpg', '.jpeg')))
-    if vid_list and vid_list[0] is not None:
-        names = [f for f in names if any(f.startswith(f'{v}_') or f.startswith(f'{v:03d}') for v in vid_list)]
-    names = names[::frame_gap]
-    if not names:
-        raise FileNotFoundError(f'no frames in {main_dir}')
-    frames = []
-    for f in names:
-        img = np.asarray(Image.open(os.path.join(main_dir, f)).convert('RGB'), dtype=np.uint8)
-        t = torch.from_numpy(img).permute(2, 0, 1)
+class FrameDir:
+    """CustomDataSet (model.py:11-70) without the DataLoader: same indexing, quirks included.
+
+    * every directory entry counts (sorted os.listdir, model.py:26-27): N_all of them;
+    * normalised time of entry i is float(i) / N_all (model.py:37);
+    * `vid_list` (when it holds no None) is a list of frame INDICES that subsets the time table only
+      (model.py:40-41) -- the file table stays whole, so item k pairs file k*gap with time frame_idx[vid_list[k*gap]];
+    * len = len(time table) // frame_gap (floor, model.py:50); item k reads position k * frame_gap (model.py:60-68);
+    * ToTensor semantics (uint8 / 255 -> fp32 CHW); a frame taller than wide is transposed (model.py:66-67)."""
+
+    def __init__(self, main_dir: str, vid_list=(None,), frame_gap: int = 1):
+        import os
+        self.main_dir = main_dir
+        self.frame_path = sorted(os.listdir(main_dir))
+        n_all = len(self.frame_path)
+        self.frame_idx = [float(x) / n_all for x in range(n_all)]
+        if vid_list is not None and None not in vid_list:
+            self.frame_idx = [self.frame_idx[i] for i in vid_list]
+        self.frame_gap = frame_gap
+
+    def __len__(self):
+        return len(self.frame_idx) // self.frame_gap
+
+    def item(self, idx: int):
+        """(uint8 CHW tensor, normalised time as a Python float) of sample idx."""
+        import os
+        import numpy as np
+        from PIL import Image
+        valid = idx * self.frame_gap
+        img = np.asarray(Image.open(os.path.join(self.main_dir, self.frame_path[valid])).convert('RGB'), dtype=np.uint8)
+        t = torch.from_numpy(img.copy()).permute(2, 0, 1)
         if t.shape[1] > t.shape[2]:
             t = t.permute(0, 2, 1)
-        frames.append(t)
-    return (torch.stack(frames).to(device).float() / 255.0).contiguous()
+        return t, self.frame_idx[valid]
+
+    def load(self, device='cuda'):
+        """All samples at once: frames [n,3,H,W] fp32 in [0,1] resident on `device`, times [n] fp32 (torch.tensor of the
+        Python doubles, as model.py:68 makes them)."""
+        if len(self) == 0:
+            raise FileNotFoundError(f'no frames in {self.main_dir}')
+        items = [self.item(k) for k in range(len(self))]
+        # ToTensor's arithmetic on the host (uint8 -> fp32, / 255 correctly rounded), then one upload: a device-side division
+        # may be compiled to a reciprocal multiply and differ in the last bit
+        frames = torch.stack([f.float().div(255.0) for f, _ in items]).contiguous().to(device)
+        return frames, torch.tensor([t for _, t in items], dtype=torch.float32)
+
+
+def load_png_dir(main_dir: str, vid_list=(None,), frame_gap: int = 1, device='cuda'):
+    """(frames [n,3,H,W] fp32 on `device`, times [n] fp32) of a frame directory with CustomDataSet's indexing (FrameDir)."""
+    return FrameDir(main_dir, vid_list, frame_gap).load(device)

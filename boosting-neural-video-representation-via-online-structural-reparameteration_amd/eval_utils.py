@@ -1,8 +1,9 @@
 """Host-side compression utilities of the evaluation path: per-tensor / per-axis affine
 quantisation (utils.py:11-67), global L1 unstructured pruning (main_eval.py:269-273, torch.nn.utils.prune
-semantics) and the entropy-coded size estimate (main_eval.py:652-729, which uses `dahuffman`; a canonical Huffman
-code has the same total length, so the bit count is reproduced without the package -- parity unpinned, the
-package is not in the reference tree).  One-shot, milliseconds: plain torch on whatever device the tensors are on."""
+semantics, which keep a pruned weight as weight_orig + weight_mask in the state dict) and the entropy-coded size estimate
+(main_eval.py:652-729, which uses `dahuffman`; an optimal prefix code over the same level histogram is computed here --
+parity of the bit count unpinned, the package is not in the reference tree; the histogram itself is pinned by
+tests/golden/prune.npz).  One-shot, milliseconds: plain torch on whatever device the tensors are on."""
 import heapq
 from collections import Counter
 from typing import Dict, Iterable, Tuple
@@ -65,10 +66,14 @@ def global_l1_prune_masks(tensors: Dict[str, torch.Tensor], amount: float) -> Di
 def huffman_total_bits(symbols: Iterable[int]) -> int:
     """Total code length of an optimal prefix code for the symbol stream (= what dahuffman's encoder emits,
     up to its end-of-stream symbol)."""
-    freq = Counter(symbols)
-    if len(freq) <= 1:
-        return sum(freq.values())            # one symbol still costs one bit each
-    heap = [(f, i, 0) for i, f in enumerate(freq.values())]
+    return huffman_bits_from_counts(Counter(symbols).values())
+
+
+def huffman_bits_from_counts(counts: Iterable[int]) -> int:
+    counts = [int(c) for c in counts]
+    if len(counts) <= 1:
+        return sum(counts)                   # one symbol still costs one bit each
+    heap = [(f, i, 0) for i, f in enumerate(counts)]
     heapq.heapify(heap)
     total = 0
     nxt = len(heap)
@@ -81,13 +86,64 @@ def huffman_total_bits(symbols: Iterable[int]) -> int:
     return total
 
 
+def pruned_state_dict(sd: Dict[str, torch.Tensor], masks: Dict[str, torch.Tensor], originals: Dict[str, torch.Tensor] = None):
+    """The state dict of a model after torch.nn.utils.prune (never removed by the reference): a pruned `X.weight` appears as
+    `X.weight_orig` (the UNMASKED values) + `X.weight_mask`, in that order behind the module's other parameters.
+    originals: unmasked values where `sd` already holds weight * mask (e.g. after a masked fine-tune)."""
+    mods, by_mod = [], {}
+    for k in sd:
+        mod = k.rsplit('.', 1)[0]
+        if mod not in by_mod:
+            by_mod[mod] = []
+            mods.append(mod)
+        by_mod[mod].append(k)
+    out = {}
+    for mod in mods:             # torch: the module's remaining parameters, then weight_orig (re-registered last), then the mask buffer
+        pruned = [k for k in by_mod[mod] if k in masks]
+        for k in by_mod[mod]:
+            if k not in masks:
+                out[k] = sd[k]
+        for k in pruned:
+            v = sd[k]
+            out[k + '_orig'] = v if originals is None or k not in originals else torch.where(masks[k] != 0, v, originals[k].to(v))
+        for k in pruned:
+            out[k + '_mask'] = masks[k].to(sd[k])
+    return out
+
+
+def fold_pruned(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """weight = weight_orig * weight_mask for every pruned pair (what torch's forward pre-hook computes)."""
+    out = {}
+    for k, v in sd.items():
+        if k.endswith('_mask'):
+            continue
+        if k.endswith('_orig'):
+            out[k[:-5]] = v * sd[k[:-5] + '_mask']
+        else:
+            out[k] = v
+    return out
+
+
 def quantized_model_bits(state_dict: Dict[str, torch.Tensor], bit: int = 8, axis: int = 0):
-    """main_eval.py:652-729: quantise every tensor, entropy-code all levels with one Huffman table.
-    Returns (de-quantised state dict, total bits, number of coded values)."""
-    new_sd, symbols = {}, []
+    """main_eval.py:652-691 on a state dict as `model.state_dict()` gives it there (pruned tensors as weight_orig +
+    weight_mask, see pruned_state_dict): every tensor is quantised -- per `axis` when it is 2-D / 4-D and not a bias
+    (main_eval.py:661), per tensor otherwise -- and ONE Huffman table codes the levels of the entries that are non-zero in the
+    tensor being quantised (main_eval.py:664-667: `mask_cpu = v != 0; quant_v_cpu[mask_cpu]`).  Q3 comes with it: a 0/1
+    weight_mask quantises to all ones (its non-zero entries have min = max = 1, scale 0), so the pruning is undone in the
+    de-quantised model, and each of its ones adds a level-0 symbol to the stream.
+    Returns (de-quantised state dict, total bits, number of coded values, {level: count}).
+    The total is that of an optimal prefix code over the level histogram; the reference takes its code lengths from
+    `dahuffman` (absent from the reference tree and from this image: parity of the bit count is unpinned -- dahuffman adds an
+    end-of-stream symbol of frequency 1 to the table, which can lengthen other codes by a bit)."""
+    new_sd, hist = {}, Counter()
+    count = 0
     for k, v in state_dict.items():
-        ax = axis if (v.dim() in (2, 4)) else -1
-        q, nv = quantize_per_tensor(v.float(), bit, ax)
-        new_sd[k] = nv
-        symbols += q.flatten().to(torch.int64).tolist()
-    return new_sd, huffman_total_bits(symbols), len(symbols)
+        large = v.dim() in (2, 4) and 'bias' not in k
+        q, nv = quantize_per_tensor(v.float(), bit, axis if large else -1)
+        new_sd[k] = nv.to(v.dtype)
+        valid = q[v != 0].flatten()
+        count += valid.numel()
+        vals, cnts = torch.unique(valid.to(torch.float64), return_counts=True)
+        for a_, c_ in zip(vals.tolist(), cnts.tolist()):
+            hist[a_] += c_
+    return new_sd, huffman_bits_from_counts(hist.values()), count, dict(hist)

@@ -36,6 +36,7 @@ def _prune_finetune(model, args, PE, ckpt_path):
             k = f'layers.{i}.{b}.weight'
             if k in named:
                 prunable[k] = named[k].detach()
+    originals = {k: v.clone() for k, v in prunable.items() if k.startswith('stem.')}     # weight_orig keeps them under the mask
     masks = eval_utils.global_l1_prune_masks(prunable, args.prune_ratio)
     zero = sum(int((m == 0).sum()) for m in masks.values())
     tot = sum(m.numel() for m in masks.values())
@@ -50,10 +51,10 @@ def _prune_finetune(model, args, PE, ckpt_path):
         gmask[k] = torch.zeros_like(m) if frozen else m
     eng.set_grad_mask(gmask)
     hw = eng.out_hw
-    frames = (odata.synthetic_video(args.synthetic, hw[0], hw[1], seed=1234) if args.synthetic
-              else odata.load_png_dir(f'../data/{args.dataset.lower()}', args.vid, args.frame_gap))
+    from .main_train import load_frames
+    frames, pos = load_frames(args, hw, eng.device, args.dataset, 0, args.frame_gap)
     n = frames.shape[0]
-    eng.set_video(frames, PE(torch.tensor([float(k) / n for k in range(n)], dtype=torch.float32)))
+    eng.set_video(frames, PE(pos))
     try:
         start_epoch = int(torch.load(ckpt_path, map_location='cpu', weights_only=True).get('epoch', args.epochs))
     except Exception:
@@ -75,6 +76,10 @@ def _prune_finetune(model, args, PE, ckpt_path):
             print(f'fine-tune epoch {epoch + 1}/{total} lr {float(st[-1, 5]):.2e} PSNR {float(st[:, 4].mean()):.2f}', flush=True)
     eng.set_grad_mask(None)
     torch.cuda.synchronize()
+    # what stays pruned in the reference's state dict after the fine-tune: the stem Linear layers (weight_orig + weight_mask;
+    # the ERB branch modules disappear in switch_to_deploy, a vanilla block keeps its pruned `branch`)
+    keep = {k: m for k, m in masks.items() if k.startswith('stem.') or args.branch_type != 'ERB'}
+    return keep, {k: v for k, v in originals.items() if k in keep}
 
 
 def main(argv=None):
@@ -83,6 +88,7 @@ def main(argv=None):
     p.add_argument('--finetune_epochs', type=int, default=100)
     p.add_argument('--cycles', type=int, default=1)
     args = p.parse_args(argv)
+    args.warmup = int(args.warmup * args.epochs)          # main_eval.py:106 (as main_train.parse_args): warm-up in epochs
     outf = os.path.join('result', args.outf, f'{args.suffix}')
     PE = utils.PositionalEncoding(args.embed)
     deploy_file = os.path.join(outf, 'model_latest_deploy.pth')
@@ -100,32 +106,37 @@ def main(argv=None):
                              branch_type=args.branch_type)
     kind = checkpoint.load_into(model, sd)
     model = model.cuda()
+    masks, originals = {}, None
     if finetune:
-        _prune_finetune(model, args, PE, path)
+        masks, originals = _prune_finetune(model, args, PE, path)
     if kind != 'deploy':
         for blk in model.layers:
             blk.switch_to_deploy() if blk.branch_type == 'ERB' else None
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     n_param = sum(v.numel() for v in sd.values())
-    if args.prune_ratio < 1 and not finetune:      # main_eval.py:551-650: prune the deploy-state weights, global L1
-        prunable = {k: v for k, v in sd.items() if k.endswith('weight')}
+    if args.prune_ratio < 1 and not finetune:
+        # main_eval.py:551-650: global L1 over the stem Linear weights and the blocks' single convs (deploy-state
+        # rbr_reparam for ERB, branch / rbr_reparam for NeRV_vanilla) -- not the head, not the biases
+        prunable = {k: v for k, v in sd.items()
+                    if k.endswith('.weight') and (k.startswith('stem.') or (k.startswith('layers.') and k.split('.')[2] in ('rbr_reparam', 'branch')))}
         masks = eval_utils.global_l1_prune_masks(prunable, args.prune_ratio)
-        for k, m in masks.items():
-            sd[k] = sd[k] * m
         kept = sum(int(m.sum()) for m in masks.values())
-        print(f'pruned {1 - kept / sum(m.numel() for m in masks.values()):.3f} of the weights')
+        print(f'global L1 prune of {len(masks)} tensors: {1 - kept / sum(m.numel() for m in masks.values()):.3f} of the weights masked')
+    # the state dict as the reference sees it from here on: pruned tensors as weight_orig + weight_mask (never removed)
+    sd = eval_utils.pruned_state_dict(sd, masks, originals)
     bits = None
     if args.quant_bit != -1:
-        sd, bits, count = eval_utils.quantized_model_bits(sd, args.quant_bit, args.quant_axis)
-        print(f'quantised to {args.quant_bit} bit: {bits / 8 / 1e6:.3f} MB entropy-coded ({bits / count:.2f} bits/param)')
-    model.load_state_dict(sd)
+        sd, bits, count, _ = eval_utils.quantized_model_bits(sd, args.quant_bit, args.quant_axis)
+        print(f'quantised to {args.quant_bit} bit: {bits / 8 / 1e6:.3f} MB entropy-coded over the {count} non-zero entries '
+              f'({bits / max(count, 1):.2f} bits each; optimal prefix code, dahuffman parity unpinned)')
+    model.load_state_dict(eval_utils.fold_pruned(sd))
     hw = [model.fc_h, model.fc_w]
     for s_ in args.strides:
         hw = [hw[0] * s_, hw[1] * s_]
-    frames = (odata.synthetic_video(args.synthetic, hw[0], hw[1], seed=1234) if args.synthetic
-              else odata.load_png_dir(f'../data/{args.dataset.lower()}', args.vid, args.test_gap))
+    from .main_train import load_frames
+    frames, pos = load_frames(args, hw, 'cuda', args.dataset, 0, args.test_gap)       # val_dataset: CustomDataSet(frame_gap=test_gap)
     n = frames.shape[0]
-    embeds = PE(torch.tensor([float(k) / n for k in range(n)], dtype=torch.float32))
+    embeds = PE(pos)
     psnrs = []
     torch.cuda.synchronize()
     t0 = time.time()

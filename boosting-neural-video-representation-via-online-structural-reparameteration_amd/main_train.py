@@ -93,42 +93,123 @@ def parse_args(argv=None):
     return args
 
 
-def load_frames(args, hw, device):
+def video_list(args, world):
+    """The independent fits of this job (one video per rank, round-robin when there are more): `--dataset a,b,c`
+    names one frame directory each (../data/<name>, main_train.py:181); with --synthetic there are max(world, 1) seeded
+    synthetic videos."""
     if args.synthetic:
-        return odata.synthetic_video(args.synthetic, hw[0], hw[1], seed=1234 + du.env_world()[0], device=device)
-    return odata.load_png_dir(f'../data/{args.dataset.lower()}', args.vid, args.frame_gap, device)
+        return [f'synthetic{v}' for v in range(max(world, 1))]
+    return [d for d in args.dataset.split(',') if d]
+
+
+def video_outf(base_outf, videos, v):
+    """Output directory of video v: the job's own directory when it fits a single video (the reference layout), else one
+    sub-directory per video -- ranks fit different videos, so no two ranks ever write the same checkpoint or log."""
+    return base_outf if len(videos) == 1 else os.path.join(base_outf, videos[v])
+
+
+def load_frames(args, hw, device, name, vid_index, gap):
+    """(frames, times) of one video: CustomDataSet indexing for a frame directory (model.py:11-70), k / n for synthetic."""
+    if args.synthetic:
+        frames = odata.synthetic_video(args.synthetic, hw[0], hw[1], seed=1234 + vid_index, device=device)
+        n = frames.shape[0]
+        frames, pos = frames, torch.tensor([float(k) / n for k in range(n)], dtype=torch.float32)
+        if gap > 1:
+            keep = [k * gap for k in range(n // gap)]
+            frames, pos = frames[keep].contiguous(), pos[keep]
+        return frames, pos
+    return odata.load_png_dir(f'../data/{name.lower()}', args.vid, gap, device)
 
 
 def save_checkpoint(args, model, eng, epoch, best_psnr, name='model_latest.pth'):
     """main_train.py:293-301,327 layout; ERB also writes the deploy copy (main_train.py:325-351)."""
     from . import checkpoint
-    opt = {'adam_m': eng.adam_m.cpu(), 'adam_v': eng.adam_v.cpu(), 'step': eng.global_step, 'layout': eng.layout}
+    opt = adam_state_dict(model, eng, args)
     checkpoint.save(os.path.join(args.outf, name), model, epoch + 1, opt, best_psnr, best_psnr)
     if args.branch_type == 'ERB':
         checkpoint.save(os.path.join(args.outf, name.replace('.pth', '_deploy.pth')), model, epoch + 1, opt, best_psnr, best_psnr,
                         deploy=True)
 
 
-def evaluate(model, eng, args):
-    """main_train.py:377-438: forward over all frames, PSNR per frame, decoder FPS."""
-    n = eng.frames.shape[0]
+def adam_state_dict(model, eng, args):
+    """The optimizer entry of a checkpoint in torch.optim.Adam's own state_dict layout (per-parameter 'step' / 'exp_avg' /
+    'exp_avg_sq' in model.parameters() order + one param group), so the reference's
+    `optimizer.load_state_dict(checkpoint['optimizer'])` (main_eval.py:409, main_train.py:207-212) reads it."""
+    state = {}
+    for i, (k, p) in enumerate(model.named_parameters()):
+        off, n = eng.layout[k]
+        state[i] = {'step': torch.tensor(float(eng.global_step)), 'exp_avg': eng.adam_m[off:off + n].view(p.shape).cpu().clone(),
+                    'exp_avg_sq': eng.adam_v[off:off + n].view(p.shape).cpu().clone()}
+    group = {'lr': args.lr, 'betas': (args.beta, 0.999), 'eps': 1e-8, 'weight_decay': 0, 'amsgrad': False, 'maximize': False,
+             'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None, 'decoupled_weight_decay': False,
+             'params': list(range(len(state)))}
+    return {'state': state, 'param_groups': [group]}
+
+
+def load_adam_state(eng, model, opt):
+    """Inverse of adam_state_dict (also accepts round 1's flat {'adam_m', 'adam_v', 'step'} form)."""
+    if not opt:
+        return
+    if 'adam_m' in opt:
+        eng.adam_m.copy_(opt['adam_m'].to(eng.device)); eng.adam_v.copy_(opt['adam_v'].to(eng.device))
+        eng.global_step = int(opt.get('step', 0))
+        return
+    for i, (k, p) in enumerate(model.named_parameters()):
+        st = opt['state'].get(i)
+        if st is None:
+            continue
+        off, n = eng.layout[k]
+        eng.adam_m[off:off + n].copy_(st['exp_avg'].reshape(-1).to(eng.device))
+        eng.adam_v[off:off + n].copy_(st['exp_avg_sq'].reshape(-1).to(eng.device))
+        eng.global_step = int(float(st['step']))
+
+
+def evaluate(model, eng, args, val=None):
+    """main_train.py:377-438: forward over the validation samples -- CustomDataSet(frame_gap=test_gap): sample k is entry
+    k * test_gap, floor(N / test_gap) of them -- PSNR per frame, decoder FPS.  val: (frames, embeds) when the validation
+    samples are not a subset of the resident training frames (frame_gap > 1)."""
+    frames, embeds = val if val is not None else (eng.frames, eng.embeds)
+    idx = list(range(frames.shape[0])) if val is not None else [k * args.test_gap for k in range(frames.shape[0] // args.test_gap)]
     psnrs = []
     torch.cuda.synchronize()
     t0 = time.time()
-    for k in range(0, n, args.test_gap):
-        img = eng.decode(eng.embeds[k])
-        stats, _ = ops.loss_stats(img, eng.frames[k:k + 1], 'L2', want_grad=False)
+    for k in idx:
+        img = eng.decode(embeds[k])
+        stats, _ = ops.loss_stats(img, frames[k:k + 1], 'L2', want_grad=False)
         psnrs.append(stats[4])
     torch.cuda.synchronize()
     dt = time.time() - t0
-    ms = [utils.msssim_fn([eng.decode(eng.embeds[k])], [eng.frames[k:k + 1]])[0, 0] for k in range(0, n, args.test_gap)]  # untimed
+    ms = [utils.msssim_fn([eng.decode(embeds[k])], [frames[k:k + 1]])[0, 0] for k in idx]  # untimed
     return float(torch.stack(psnrs).mean()), len(psnrs) / dt, float(torch.stack(ms).mean())
 
 
 def train(args):
+    """One independent fit per video; the videos of the job are dealt round-robin to the ranks (dist_utils.shard_videos), each
+    into its own output directory, so ranks never write the same file.  Returns the best train PSNR of this rank's last fit."""
     rank, local, world = du.env_world()
     torch.cuda.set_device(local)
     dist = du.init()
+    videos = video_list(args, world)
+    mine = du.shard_videos(len(videos), world, rank)
+    best, frames_done, steps_done = 0.0, 0.0, 0.0
+    start = time.time()
+    base_outf = args.outf
+    for v in mine:
+        args.outf = video_outf(base_outf, videos, v)
+        b, f, st = fit_video(args, videos[v], v, rank)
+        best, frames_done, steps_done = b, frames_done + f, steps_done + st
+    args.outf = base_outf
+    secs = time.time() - start
+    recs = du.gather_records(dist, [best, 0.0, frames_done, secs, steps_done], device=f'cuda:{local}' if dist is not None else 'cpu')
+    if rank == 0:
+        agg = du.aggregate(recs, max(r[3] for r in recs))
+        print(f'Training complete in {secs:.1f}s: {agg}', flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    return best
+
+
+def fit_video(args, name, vid_index, rank):
     torch.manual_seed(args.manualSeed)                              # main_train.py:162
     PE = utils.PositionalEncoding(args.embed)
     args.embed_length = PE.embed_length
@@ -139,10 +220,13 @@ def train(args):
                              deploy=args.deploy, branch_type=args.branch_type)
     total_params = sum(p.numel() for p in model.parameters()) / 1e6
     eng = oeng.TrainEngine(model, loss_type=args.loss_type, beta=args.beta, precision=args.precision)
-    frames = load_frames(args, eng.out_hw, eng.device)
+    frames, pos = load_frames(args, eng.out_hw, eng.device, name, vid_index, args.frame_gap)
     n = frames.shape[0]
-    pos = torch.tensor([float(k) / n for k in range(n)], dtype=torch.float32)      # model.py:37,68
-    eng.set_video(frames, PE(pos))
+    eng.set_video(frames, PE(pos))                                  # pos: model.py:37,68
+    val = None
+    if args.frame_gap != 1:                                         # the validation samples are not a subset of the training ones
+        vf, vp = load_frames(args, eng.out_hw, eng.device, name, vid_index, args.test_gap)
+        val = (vf, PE(vp).to(eng.device))
     os.makedirs(args.outf, exist_ok=True)
     log = open(os.path.join(args.outf, f'rank{rank}.txt'), 'a')
     print(f'{args}\n Model Params: {total_params}M', file=log, flush=True)
@@ -159,29 +243,25 @@ def train(args):
         st = eng.stats(len(entries))                                 # syncs once per epoch
         train_psnr = st[:, 4].mean()
         best = torch.maximum(best, train_psnr)
-        line = (f'[{time.strftime("%Y/%m/%d %H:%M:%S")}] Rank:{rank}, Epoch[{epoch + 1}/{args.epochs}], lr:{st[-1, 5]:.2e} '
+        line = (f'[{time.strftime("%Y/%m/%d %H:%M:%S")}] Rank:{rank}, Video:{name}, Epoch[{epoch + 1}/{args.epochs}], lr:{st[-1, 5]:.2e} '
                 f'PSNR: {train_psnr:.2f}, loss: {st[:, 0].mean():.5f}, {(time.time() - start) / (epoch + 1):.3f} s/epoch')
         if epoch % max(1, args.print_freq // 10) == 0 or epoch == args.epochs - 1:
             print(line, flush=True)
         print(line, file=log, flush=True)
         is_eval = (epoch + 1) % args.eval_freq == 0 or epoch > args.epochs - 10     # main_train.py:303
         if is_eval:
-            val_psnr, fps, val_msssim = evaluate(model, eng, args)
+            val_psnr, fps, val_msssim = evaluate(model, eng, args, val)
             msg = f'Eval Epoch[{epoch + 1}] PSNR {val_psnr:.2f} MS-SSIM {val_msssim:.4f} decode FPS {fps:.1f}'
             print(msg, flush=True)
             print(msg, file=log, flush=True)
         if (args.ckpt_freq and (epoch + 1) % args.ckpt_freq == 0) or (not args.ckpt_freq and is_eval) or epoch == args.epochs - 1:
             save_checkpoint(args, model, eng, epoch, best)
     torch.cuda.synchronize()
-    secs = time.time() - start
-    recs = du.gather_records(dist, [float(best), 0.0, float(args.epochs * steps_per_epoch), secs, float(eng.global_step)],
-                             device=eng.device if dist is not None else 'cpu')
-    if rank == 0:
-        agg = du.aggregate(recs, max(r[3] for r in recs))
-        print(f'Training complete in {secs:.1f}s: {agg}', flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
-    return float(best)
+    sc = eng.scale_state()
+    if sc['skipped']:
+        print(f'loss scale: {sc["skipped"]} steps skipped (non-finite gradients), scale now {sc["scale"]:g}', file=log, flush=True)
+    log.close()
+    return float(best), float(args.epochs * steps_per_epoch), float(eng.global_step)
 
 
 def main(argv=None):

@@ -207,5 +207,123 @@ def test_prune_and_huffman(orn):
     n = len(syms)
     ent = -sum(c / n * math.log2(c / n) for c in (5, 9, 12, 13, 16, 45)) * n
     assert ent <= 224 < ent + n
-    sd, bits, count = eval_utils.quantized_model_bits({'w': torch.randn(6, 10), 'b': torch.randn(6)}, 8, 0)
-    assert count == 66 and 0 < bits <= 66 * 9 and sd['w'].shape == (6, 10)
+    sd, bits, count, hist = eval_utils.quantized_model_bits({'w': torch.randn(6, 10), 'b': torch.randn(6)}, 8, 0)
+    assert count == 66 and 0 < bits <= 66 * 9 and sd['w'].shape == (6, 10) and sum(hist.values()) == 66
+
+
+def test_prune_then_quantise_matches_reference_walk(orn):
+    """G9 / Q3 (tests/golden/prune.npz, made by the reference's Generator + torch prune + quantize_per_tensor): deploy-mode tiny
+    ERB model, global L1 prune 0.4 over the stem Linear weights and the rbr_reparam convs, then the quantisation walk of
+    main_eval.py:659-669.  Pinned: the pruned state dict's key list (weight_orig / weight_mask pairs), every de-quantised
+    tensor bit for bit (the masks come back as all ones: quantisation un-prunes), the number of coded entries per tensor
+    (non-zero entries only) and the level histogram the Huffman table is built from."""
+    from orn_amd import eval_utils
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'prune.npz'))
+    dsd = {k[len('q3/deploy_sd/'):]: torch.from_numpy(g[k]) for k in g.files if k.startswith('q3/deploy_sd/')}
+    keys = [str(k) for k in g['q3/keys']]
+    order = [k for k in keys if not k.endswith('_mask')]
+    sd = {k.replace('weight_orig', 'weight'): dsd[k.replace('weight_orig', 'weight')] for k in order}
+    prunable = {k: v for k, v in sd.items()
+                if k.endswith('.weight') and (k.startswith('stem.') or (k.startswith('layers.') and k.split('.')[2] == 'rbr_reparam'))}
+    masks = eval_utils.global_l1_prune_masks(prunable, 0.4)
+    psd = eval_utils.pruned_state_dict(sd, masks)
+    assert list(psd.keys()) == keys
+    new_sd, bits, count, hist = eval_utils.quantized_model_bits(psd, 8, 0)
+    for k in keys:
+        assert torch.equal(new_sd[k], torch.from_numpy(g[f'q3/new/{k}'])), k
+        nv = int(g[f'q3/n_valid/{k}'][0])
+        assert nv == int((psd[k] != 0).sum()), k
+        if k.endswith('_mask'):
+            assert torch.equal(new_sd[k], torch.ones_like(new_sd[k]))          # Q3
+    assert count == int(g['q3/n_symbols'][0])
+    ref_hist = {float(v): int(c) for v, c in zip(g['q3/level_values'], g['q3/level_counts'])}
+    assert hist == ref_hist
+    assert bits == eval_utils.huffman_bits_from_counts(ref_hist.values()) and count * 1 <= bits <= count * 9
+    # the folded model is un-pruned (orig * ones) but quantised
+    folded = eval_utils.fold_pruned(new_sd)
+    assert set(folded) == set(sd) and torch.equal(folded['stem.0.weight'], new_sd['stem.0.weight_orig'])
+
+
+def test_finetune_lr_matches_reference(orn):
+    """Q2: the LR of the prune fine-tune (main_eval.py:474) for epochs 300..399 of a 300-epoch checkpoint, against the
+    reference's adjust_lr (tests/golden/prune.npz q2): the cosine evaluated past its end with warm-up 60 EPOCHS -- main_eval
+    normalises --warmup 0.2 to int(0.2 * epochs) exactly as main_train does."""
+    from orn_amd import utils, main_eval, main_train
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'prune.npz'))
+    args = main_train.build_parser().parse_args(['--epochs', '300', '--lr', '0.0005', '--warmup', '0.2'])     # README.md:56-61
+    args.warmup = int(args.warmup * args.epochs)
+    assert args.warmup == 60 and args.epochs == 300 and args.lr == 5e-4
+    for epoch, it, lr in g['q2/finetune_lr']:
+        mine = utils.lr_value(int(epoch) % 400, int(it), 132, args)
+        assert mine == lr, (epoch, it, mine, lr)
+    import inspect
+    assert 'args.warmup = int(args.warmup * args.epochs)' in inspect.getsource(main_eval.main)
+
+
+def _write_frames(d, n, portrait=False):
+    from PIL import Image
+    rng = np.random.RandomState(7)
+    imgs = []
+    for k in range(n):
+        a = rng.randint(0, 256, size=((12, 8, 3) if portrait else (8, 12, 3)), dtype=np.uint8)
+        Image.fromarray(a).save(os.path.join(d, f'f{k:04d}.png'))
+        imgs.append(a)
+    return imgs
+
+
+def test_frame_dir_matches_customdataset(orn, tmp_path):
+    """N4: FrameDir against CustomDataSet's indexing (model.py:11-70) on a temporary PNG directory: odd frame count with
+    frame_gap 2 (floor(N / gap) samples, sample k = file k*gap at time k*gap / N_all), a vid_list of frame indices (subsets the
+    TIME table only, model.py:40-41), ToTensor scaling, and the portrait -> landscape transpose (model.py:66-67)."""
+    from orn_amd import data
+    d = tmp_path / 'land'
+    d.mkdir()
+    imgs = _write_frames(str(d), 7)
+    fd = data.FrameDir(str(d), (None,), 2)
+    assert len(fd) == 3                                           # 7 // 2, not ceil
+    frames, t = fd.load('cpu')
+    assert frames.shape == (3, 3, 8, 12) and frames.dtype == torch.float32
+    for k in range(3):
+        want = torch.from_numpy(imgs[2 * k]).permute(2, 0, 1).float() / 255.0
+        assert torch.equal(frames[k], want)
+        assert t[k].item() == torch.tensor(float(2 * k) / 7).item()
+    fd1 = data.FrameDir(str(d), (None,), 1)
+    assert len(fd1) == 7 and fd1.item(6)[1] == 6.0 / 7
+    # vid_list: indices into the time table; the file table is not subset (reference behaviour, kept)
+    fv = data.FrameDir(str(d), [5, 1, 3], 1)
+    assert len(fv) == 3
+    f0, t0 = fv.item(0)
+    assert t0 == 5.0 / 7 and torch.equal(f0, torch.from_numpy(imgs[0]).permute(2, 0, 1))
+    assert fv.item(2)[1] == 3.0 / 7
+    assert len(data.FrameDir(str(d), [5, 1, 3], 2)) == 1
+    # portrait frames come back transposed to landscape
+    dp = tmp_path / 'port'
+    dp.mkdir()
+    pimgs = _write_frames(str(dp), 2, portrait=True)
+    pf, _ = data.load_png_dir(str(dp), (None,), 1, 'cpu')
+    assert pf.shape == (2, 3, 8, 12)
+    assert torch.equal(pf[1], (torch.from_numpy(pimgs[1]).permute(2, 0, 1).permute(0, 2, 1).float() / 255.0))
+    with pytest.raises(FileNotFoundError):
+        data.load_png_dir(str(tmp_path / 'land'), (None,), 8, 'cpu')
+
+
+def test_per_rank_outputs_do_not_collide(orn):
+    """Multi-rank CLI: the job's videos are dealt round-robin, one output directory per video."""
+    from orn_amd import main_train, dist_utils as du
+
+    class A:
+        synthetic, dataset = 0, 'beauty,bosphorus,honeybee,jockey,readysetgo,shakendry,yachtride'
+    vids = main_train.video_list(A, 8)
+    assert len(vids) == 7
+    seen = {}
+    for rank in range(8):
+        for v in du.shard_videos(len(vids), 8, rank):
+            out = main_train.video_outf('result/uvg', vids, v)
+            assert out not in seen, (out, rank, seen[out])
+            seen[out] = rank
+    assert len(seen) == 7 and seen['result/uvg/beauty'] == 0 and du.shard_videos(7, 8, 7) == []
+    A.synthetic = 12
+    sv = main_train.video_list(A, 2)
+    assert sv == ['synthetic0', 'synthetic1'] and main_train.video_outf('o', sv, 1) == 'o/synthetic1'
+    A.synthetic, A.dataset = 0, 'bunny'
+    assert main_train.video_outf('result/b', main_train.video_list(A, 1), 0) == 'result/b'       # single video: reference layout

@@ -284,14 +284,132 @@ def golden_utils(ref_utils):
     np.savez_compressed(os.path.join(OUT, 'utils.npz'), **out)
 
 
+ERB_BRANCH_MODULES = ('rbr_3x3_branch', 'rbr_3x1_branch', 'rbr_1x3_branch', 'rbr_1x1_3x3_1x1_branch_1x1_1',
+                      'rbr_1x1_3x3_1x1_branch_3x3', 'rbr_1x1_3x3_1x1_branch_1x1_2')
+
+
+def golden_prune(ref_model, ref_utils):
+    """G9: the prune -> fine-tune quirk Q1 and the prune -> quantise quirk Q3 of main_eval.py, produced by the
+    reference's own modules (NeRVBlock, Generator, quantize_per_tensor) + torch.nn.utils.prune.  main_eval.py itself cannot be
+    imported here (torchvision / thop / dahuffman are absent), so the few glue lines that select the modules
+    (main_eval.py:296-340 train-mode ERB, :571-587 deploy-mode ERB) and walk the state dict (main_eval.py:659-669) are
+    restated below; every number comes out of reference code."""
+    import torch.nn.utils.prune as prune
+    out = {}
+    pe = ref_utils.PositionalEncoding('1.25_40')
+    # ---- Q1: train-mode ERB, global L1 prune 0.4, three Adam steps (main_eval.py:296-350, 450-499) --------------------
+    torch.manual_seed(1)
+    gen = make_generator(ref_model, 80, '32_1', '3_4_8', [2, 2], 8, 'ERB')
+    sd0 = {k: v.detach().clone() for k, v in gen.state_dict().items()}
+    mods = []
+    for k, v in gen.named_parameters():                      # main_eval.py:296-302
+        if 'weight' in k and 'stem' in k:
+            mods.append((f'stem.{int(k.split(".")[1])}', gen.stem[int(k.split('.')[1])]))
+    for li, layer in enumerate(gen.layers):                  # main_eval.py:305-340
+        for b in ERB_BRANCH_MODULES:
+            if hasattr(layer, b):
+                mods.append((f'layers.{li}.{b}', getattr(layer, b)))
+    prune.global_unstructured([(m, 'weight') for _, m in mods], pruning_method=prune.L1Unstructured, amount=0.4)
+    out['q1/pruned_modules'] = np.array([n for n, _ in mods])
+    for n, m in mods:
+        out[f'q1/mask/{n}.weight'] = _np(m.weight_mask)
+    fused0 = [layer.get_equivalent_kernel_bias() for layer in gen.layers]
+    for li, (wf, bf) in enumerate(fused0):
+        out[f'q1/fused0/{li}/wf'] = _np(wf)
+        out[f'q1/fused0/{li}/bf'] = _np(bf)
+    opt = torch.optim.Adam(gen.parameters(), betas=(0.5, 0.999))
+    g = torch.Generator().manual_seed(5)
+    frames = torch.rand(3, 3, 12, 16, generator=g)
+    pos = torch.tensor([0.0, 1.0 / 3, 2.0 / 3], dtype=torch.float32)
+    out['q1/frames'] = _np(frames)
+    out['q1/embeds'] = _np(pe(pos))
+    lr = 1e-3
+    out['q1/lr'] = np.array([lr])
+    losses = []
+    for it in range(3):
+        img = gen(pe(pos[it:it + 1]))[0]
+        loss = torch.mean(torch.abs(img - frames[it:it + 1]))            # loss_type L1 (utils.py:143-144)
+        for gp in opt.param_groups:
+            gp['lr'] = lr
+        opt.zero_grad()
+        loss.backward(retain_graph=True)                               # main_eval.py:480
+        if it == 0:
+            opt.state.clear()                                          # main_eval.py:496-497
+        opt.step()
+        losses.append(float(loss))
+    out['q1/losses'] = np.array(losses)
+    sd1 = gen.state_dict()
+    out['q1/keys_after'] = np.array(list(sd1.keys()))
+    changed = []
+    for k, v in sd1.items():
+        base = sd0.get(k, sd0.get(k.replace('weight_orig', 'weight')))
+        if base is not None and not torch.equal(v, base):
+            changed.append(k)
+        if not k.endswith('_mask'):
+            out[f'q1/sd_after/{k}'] = _np(v)
+    out['q1/changed'] = np.array(changed)
+    for li, layer in enumerate(gen.layers):
+        wf, bf = layer.get_equivalent_kernel_bias()
+        out[f'q1/fused3/{li}/wf'] = _np(wf)
+        out[f'q1/fused3/{li}/bf'] = _np(bf)
+    # ---- Q3: deploy-mode ERB, global L1 prune 0.4, then the quantisation walk (main_eval.py:571-587, 659-669) ---------
+    torch.manual_seed(1)
+    gen = make_generator(ref_model, 80, '32_1', '3_4_8', [2, 2], 8, 'ERB')
+    for layer in gen.layers:
+        layer.switch_to_deploy()
+    dsd0 = {k: v.detach().clone() for k, v in gen.state_dict().items()}
+    for k, v in dsd0.items():
+        out[f'q3/deploy_sd/{k}'] = _np(v)
+    mods = []
+    for k, v in gen.named_parameters():
+        if 'weight' in k and 'stem' in k:
+            mods.append(gen.stem[int(k.split('.')[1])])
+    for layer in gen.layers:
+        if hasattr(layer, 'rbr_reparam'):
+            mods.append(layer.rbr_reparam)
+    prune.global_unstructured([(m, 'weight') for m in mods], pruning_method=prune.L1Unstructured, amount=0.4)
+    cur = gen.state_dict()
+    out['q3/keys'] = np.array(list(cur.keys()))
+    levels = []
+    for k, v in cur.items():                                 # main_eval.py:660-669
+        large_tf = (v.dim() in {2, 4} and 'bias' not in k)
+        quant_v, new_v = ref_utils.quantize_per_tensor(v, 8, 0 if large_tf else -1)
+        valid = quant_v.detach().cpu()[(v.detach().cpu() != 0)]
+        levels.append(valid.flatten())
+        out[f'q3/new/{k}'] = _np(new_v)
+        out[f'q3/n_valid/{k}'] = np.array([valid.numel()])
+    cat = torch.cat(levels)
+    uniq, counts = np.unique(np.array(cat.tolist()), return_counts=True)       # main_eval.py:676-677
+    out['q3/level_values'] = uniq
+    out['q3/level_counts'] = counts
+    out['q3/n_symbols'] = np.array([cat.numel()])
+    # ---- Q2: the fine-tune LR (main_eval.py:474: adjust_lr(optimizer, epoch % total_epochs, i, data_size, args) with epoch
+    # continuing from the checkpoint's 300, total_epochs = 300 + 100, args.epochs = 300, args.warmup = int(0.2 * 300)) -------
+    class _A:
+        lr, epochs, warmup, lr_type, lr_steps = 5e-4, 300, int(0.2 * 300), 'cosine', []
+
+    class _Opt:
+        param_groups = [{'lr': 0.0}]
+    tab = []
+    for epoch in range(300, 400):
+        for it in (0, 66):
+            tab.append([epoch, it, ref_utils.adjust_lr(_Opt, epoch % 400, it, 132, _A)])
+    out['q2/finetune_lr'] = np.array(tab, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'prune.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref_model, ref_utils = _import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == 'prune':      # regenerate only the G9 fixture
+        golden_prune(ref_model, ref_utils)
+        return
     golden_merge(ref_model)
     golden_block(ref_model)
     golden_generator(ref_model, ref_utils)
     golden_utils(ref_utils)
+    golden_prune(ref_model, ref_utils)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
