@@ -256,6 +256,10 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
             m.dT = e->L[i].dT; m.dw1p = e->L[i].dw1p;
             m.dw2 = grads ? grads + l.w2 : nullptr; m.dw3 = grads ? grads + l.w3 : nullptr;
             m.dw2t = e->L[i].dw2t;
+            m.half_kind = 0; m.s2 = l.s * l.s; m.Cp = ORN_FAST_C; m.wb = m.wd = nullptr; m.biasp = nullptr;
+            if (i >= e->ff) {        // the merged kernel's 16-bit operand copies come out of the merge itself
+                m.half_kind = d->precision; m.wb = e->L[i].wb; m.wd = e->L[i].wd; m.biasp = e->L[i].biasp;
+            }
         }
         int rc = orn_merge_groups_build(e->merge_tables, d->n_layers, ml, d->precision != 0);
         if (rc == 0 && d->precision != 0) {
@@ -387,12 +391,14 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
         // launches (T, then S with the bias merge b3x3 + (b1x3 + b3x1) in its first tile column), each carrying one of
         // the stem's two linear layers as extra work-groups
         ORN_TRY(orn_launch_merge_group_linear(e->merge_tables, 0, e->merge_tiles[0], lin1, st));
-        ORN_TRY(orn_launch_merge_group_linear(e->merge_tables, 1, e->merge_tiles[1], lin2, st));
+        int pk_blocks = 0;
+        const void *pk = (keep_z && e->mh_host) ? orn_merge_h16_pack(e->mh_host, &pk_blocks) : nullptr;   // training step, 16-bit modes
+        ORN_TRY(orn_launch_merge_group_linear(e->merge_tables, 1, e->merge_tiles[1], lin2, st, pk, pk_blocks));
     } else {
         ORN_TRY(orn_launch_linear_silu(lin1.x, lin1.row_idx, lin1.row_stride, lin1.w, lin1.bias, 1, lin1.K, lin1.N, lin1.pre, lin1.y, st));
         ORN_TRY(orn_launch_linear_silu(lin2.x, nullptr, 0, lin2.w, lin2.bias, 1, lin2.K, lin2.N, lin2.pre, lin2.y, st));
     }
-    if (ff < nl) {      // bf16 operand copies of every fast layer's merged kernel, one launch
+    if (ff < nl && !d.erb) {      // 16-bit operand copies of every fast layer's kernel, one launch (ERB: written by the merge's S launch)
         OrnPrepLayer pl[ORN_MAX_LAYERS];
         for (int i = ff; i < nl; ++i) {
             const orn_layer_desc &l = d.layer[i];

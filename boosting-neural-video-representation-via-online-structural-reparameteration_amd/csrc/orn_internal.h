@@ -45,12 +45,17 @@ struct OrnMergeLayer {
     const float *g;                                   // dL/dWf (in the gradient arena)
     float *dT, *dw1p, *dw2, *dw3;                     // backward scratch / outputs
     float *dw2t;                                      // 16-bit modes: dW2 tap-major [9][O][2C], interleaved by the tail kernel
+    // 16-bit fast layers (engine): the S GEMM's epilogue also writes the conv kernels' operand copies (half_kind 1 bf16 / 2 fp16)
+    int half_kind, s2, Cp;
+    void *wb, *wd;
+    float *biasp;
 };
 size_t orn_merge_group_bytes();
 int orn_merge_groups_build(void *dev_tables, int n_layers, const OrnMergeLayer *L, int bwd_h16);
 int orn_merge_group_tiles(int which, int n_layers, const OrnMergeLayer *L);
 int orn_launch_merge_group(const void *dev_tables, int which, int tiles, hipStream_t st);
-int orn_launch_merge_group_linear(const void *dev_tables, int which, int tiles, const OrnLinearJob &job, hipStream_t st);
+int orn_launch_merge_group_linear(const void *dev_tables, int which, int tiles, const OrnLinearJob &job, hipStream_t st,
+                                  const void *pack = nullptr, int pack_blocks = 0);   // pack: trailing parameter-side pack jobs (orn_merge_h16_pack)
 int orn_launch_merge_bias(const float *b3x3, const float *b1x3, const float *b3x1, int O, float *bf, hipStream_t st);
 int orn_launch_merge_bwd_tail(const float *g, const float *dbf, int C, int O, float *d3x3, float *db3x3, float *d3x1,
                               float *db3x1, float *d1x3, float *db1x3, const float *dw1p, float *dw1, hipStream_t st);
@@ -61,6 +66,7 @@ size_t orn_merge_h16_table_bytes();
 size_t orn_merge_h16_host_bytes();
 int orn_merge_h16_build(void *dev_tables, void *host, int n_layers, const OrnMergeLayer *L, void *const *bufs, OrnScaleState *sc);
 int orn_launch_merge_h16_bwd(const void *dev_tables, const void *host, hipStream_t st);
+const void *orn_merge_h16_pack(const void *host, int *fwd_blocks);
 
 // per-layer elementwise tails of the merge, all layers per launch
 struct OrnMergeMisc {

@@ -5,6 +5,7 @@
 // every output element is a SINGLE k-ordered fmaf chain starting from +0.0f -- the summation order
 // oracle/merge_ref.c specifies -- so the forward is bit-exact against the CPU oracle.
 #include "orn_internal.h"
+#include "orn_merge_pack.h"
 
 struct GemmP {
     const float *A, *B;
@@ -25,6 +26,12 @@ struct GemmP {
     // 16-bit MFMA variant (merge backward in the 16-bit engine modes): operands are multiplied by sa / sb when they
     // are rounded to IEEE half (gradient operands ~1e-6 would be subnormal), the result by so = 1/(sa*sb)
     float sa, sb, so;
+    // epilogue 1, optional (16-bit engine modes): the merged kernel also leaves in the two 16-bit operand layouts of the conv
+    // kernels (what k_prep_weights_bf16_all would otherwise re-read Wf for): wb [9][O'][Cp], wd [9][Cp][O'] with flipped
+    // taps, o' = (o % s2) * Cn + o / s2; the bias column writes biasp [O'].  half_kind: 1 = bf16, 2 = IEEE half.
+    void *wb, *wd;
+    float *biasp;
+    int half_kind, s2, Cn, Cp;
 };
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -102,7 +109,11 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, int bx, int by, int bz
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int gm = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-            if (gm < p.M) p.bf[gm] = p.b3x3[gm] + (p.b1x3[gm] + p.b3x1[gm]);     // model.py:476,496
+            if (gm < p.M) {
+                const float b = p.b3x3[gm] + (p.b1x3[gm] + p.b3x1[gm]);     // model.py:476,496
+                p.bf[gm] = b;
+                if (p.half_kind) p.biasp[(gm % p.s2) * p.Cn + gm / p.s2] = b;
+            }
         }
     }
     if (gn >= p.N) return;
@@ -117,6 +128,19 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, int bx, int by, int bz
             const float p13 = (ii == 1) ? p.w1x3[oc * 3 + jj] : 0.f;
             const float p31 = (jj == 1) ? p.w3x1[oc * 3 + ii] : 0.f;
             r = (p.w3x3[(long)gm * p.N + gn] + (p13 + p31)) + r;   // association of model.py:475,495
+            if (p.half_kind) {
+                const int op = (gm % p.s2) * p.Cn + gm / p.s2;
+                const size_t ib = ((size_t)ij * p.M + op) * p.Cp + c, id = ((size_t)(8 - ij) * p.Cp + c) * p.M + op;
+                if (p.half_kind == 1) {
+                    const __bf16 h = (__bf16)r;
+                    reinterpret_cast<__bf16 *>(p.wb)[ib] = h;
+                    reinterpret_cast<__bf16 *>(p.wd)[id] = h;
+                } else {
+                    const _Float16 h = (_Float16)r;
+                    reinterpret_cast<_Float16 *>(p.wb)[ib] = h;
+                    reinterpret_cast<_Float16 *>(p.wd)[id] = h;
+                }
+            }
         }
         C[(long)gm * p.scm + (long)gn * p.scn] = r;
     }
@@ -218,9 +242,18 @@ __global__ void __launch_bounds__(256) k_gemm_f32_grouped(const GemmGroup *__res
 
 // The same launch with one of the stem's linear layers riding along as trailing work-groups (4 output neurons each): the
 // stem and the merge are independent latency-bound chains at the head of the step, and a graph node costs ~5 us by itself.
-__global__ void __launch_bounds__(256) k_gemm_f32_grouped_linear(const GemmGroup *__restrict__ g, OrnLinearJob job, int gemm_tiles)
+__global__ void __launch_bounds__(256) k_gemm_f32_grouped_linear(const GemmGroup *__restrict__ g, OrnLinearJob job, int gemm_tiles, int lin_blocks,
+                                                                 MhPackAll pack)
 {
-    // the GEMM tiles are the long latency chains: they are dispatched first, the short linear work-groups behind them
+    // the GEMM tiles are the long latency chains: they are dispatched first, the short work-groups behind them: the stem's
+    // linear layer, then (16-bit engine modes, S launch) the parameter-side half copies of the merge BACKWARD's operands
+    if ((int)blockIdx.x >= gemm_tiles + lin_blocks) {
+        __shared__ float tile[64][65];
+        int layer, pjob;
+        const int blk = mh_pack_decode(pack, true, (int)blockIdx.x - gemm_tiles - lin_blocks, layer, pjob);
+        mh_pack_block(pack, layer, pjob, blk, tile);
+        return;
+    }
     if ((int)blockIdx.x >= gemm_tiles) {
         orn_linear_silu_wave(job, (blockIdx.x - gemm_tiles) * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
         return;
@@ -435,7 +468,12 @@ int orn_merge_groups_build(void *dev_tables, int n_layers, const OrnMergeLayer *
     for (int i = 0; i < n_layers; ++i) {
         const OrnMergeLayer &l = L[i];
         group_add(h[0], prob_T(l.w1, l.w2, l.C, l.O, l.T), 9);
-        { GemmP q = prob_S(l.w3x3, l.w3x1, l.w1x3, l.w3, l.T, l.C, l.O, l.wf); q.b3x3 = l.b3x3; q.b1x3 = l.b1x3; q.b3x1 = l.b3x1; q.bf = l.bf; group_add(h[1], q, 1); }
+        {
+            GemmP q = prob_S(l.w3x3, l.w3x1, l.w1x3, l.w3, l.T, l.C, l.O, l.wf);
+            q.b3x3 = l.b3x3; q.b1x3 = l.b1x3; q.b3x1 = l.b3x1; q.bf = l.bf;
+            if (l.half_kind) { q.half_kind = l.half_kind; q.wb = l.wb; q.wd = l.wd; q.biasp = l.biasp; q.s2 = l.s2; q.Cn = l.O / l.s2; q.Cp = l.Cp; }
+            group_add(h[1], q, 1);
+        }
         // gradient operands (dWf, dT ~ 1e-6) are scaled by 2^14 when rounded to half; weights are not
         const float GS = 16384.0f;
         GemmP q;
@@ -475,11 +513,14 @@ int orn_launch_merge_group(const void *dev_tables, int which, int tiles, hipStre
 }
 
 // fp32 groups only (which = 0 / 1: the forward merge)
-int orn_launch_merge_group_linear(const void *dev_tables, int which, int tiles, const OrnLinearJob &job, hipStream_t st)
+int orn_launch_merge_group_linear(const void *dev_tables, int which, int tiles, const OrnLinearJob &job, hipStream_t st, const void *pack,
+                                  int pack_blocks)
 {
     const GemmGroup *g = (const GemmGroup *)dev_tables + which;
     const int lin_blocks = orn_cdiv(job.N, 4);
-    hipLaunchKernelGGL(k_gemm_f32_grouped_linear, dim3(tiles + lin_blocks), dim3(256), 0, st, g, job, tiles);
+    MhPackAll pk = {};
+    if (pack && pack_blocks > 0) pk = *(const MhPackAll *)pack; else pack_blocks = 0;
+    hipLaunchKernelGGL(k_gemm_f32_grouped_linear, dim3(tiles + lin_blocks + pack_blocks), dim3(256), 0, st, g, job, tiles, lin_blocks, pk);
     ORN_LAUNCH_CHECK("merge_group_linear");
     return 0;
 }

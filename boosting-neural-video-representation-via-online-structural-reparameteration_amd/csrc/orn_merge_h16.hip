@@ -14,16 +14,12 @@
 //
 // (E = 9C; dT is produced directly in its two consumer layouts, in half, still carrying the 2^14 scale.)
 #include "orn_internal.h"
+#include "orn_merge_pack.h"
 #include <new>
 
-typedef _Float16 mh16;
 typedef __attribute__((ext_vector_type(8))) _Float16 mh16x8;
 typedef __attribute__((ext_vector_type(16))) float mf32x16;
 
-#define MH_GS 16384.0f            // gradient operands are multiplied by 2^14 when rounded to half (|dWf| ~ 1e-6)
-
-__host__ __device__ static inline int r16(int x) { return (x + 15) / 16 * 16; }
-__host__ __device__ static inline int r32(int x) { return (x + 31) / 32 * 32; }
 
 // ---- buffer sizes (halfs) of one layer -------------------------------------------------------------------------
 struct MhSizes { size_t gh, gt, th, w3t, w1h, w2p, dtt, dtc; };
@@ -51,76 +47,13 @@ size_t orn_merge_h16_layer_halfs(int C, int O)
     return tot;
 }
 
-// ---- pack ----------------------------------------------------------------------------------------------------
-struct MhPackLayer {
-    int C, O;
-    const float *g, *T, *w1, *w2, *w3;
-    mh16 *gh, *gt, *th, *w3t, *w1h, *w2p;
-};
-#define MH_JOBS 6
-#define MH_CPT 8
-struct MhPackAll {
-    int n;
-    int blk_start[MH_JOBS * ORN_MAX_LAYERS + 1];   // 1-D grid: block ranges of the (layer, job) pairs, job-major within a layer
-    MhPackLayer l[ORN_MAX_LAYERS];
-    OrnScaleState *sc;   // optional: an overflow of the scaled half copy of G raises its flag (the step is then skipped)
-};
-
-// job 0: G -> Gh (x 2^14);  1: T -> Th;  2: W1 -> W1h   (row-major copies into padded rows, one element per thread)
-// job 3: G -> GT (x 2^14);  4: W3 -> W3T;  5: W2 [m][(k,ij)] -> W2p [ij][k][m]   (64x64 tile transposes through LDS:
-//        coalesced fp32 reads along the source rows, coalesced half writes along the destination rows)
-__global__ void __launch_bounds__(256) k_merge_pack(MhPackAll a)
+// ---- pack (orn_merge_pack.h): the gradient-side jobs; the parameter-side ones ride along the forward merge ---------
+__global__ void __launch_bounds__(256) k_merge_pack(MhPackAll a, int fwd)
 {
     __shared__ float tile[64][65];
-    int pj = 0;
-    while (pj + 1 < MH_JOBS * a.n && (int)blockIdx.x >= a.blk_start[pj + 1]) ++pj;
-    const MhPackLayer &l = a.l[pj / MH_JOBS];
-    const int job = pj - (pj / MH_JOBS) * MH_JOBS;
-    const int C = l.C, O = l.O, E = 9 * C, K2 = 2 * C;
-    const int blk = blockIdx.x - a.blk_start[pj];
-    if (job < 3) {
-        // MH_CPT elements per thread (the dispatcher, not HBM, bounds a launch of ten thousand one-element work-groups)
-        const float *src = job == 0 ? l.g : (job == 1 ? l.T : l.w1);
-        mh16 *dst = job == 0 ? l.gh : (job == 1 ? l.th : l.w1h);
-        const int Q = job == 2 ? C : E;
-        const size_t n = (size_t)(job == 2 ? K2 : O) * Q;
-        const float sc = job == 0 ? MH_GS : 1.0f;
-        const int ldd = r16(Q);
-#pragma unroll
-        for (int i = 0; i < MH_CPT; ++i) {
-            const size_t idx = ((size_t)blk * MH_CPT + i) * 256 + threadIdx.x;
-            if (idx < n) {
-                const int r = (int)(idx / Q), q = (int)(idx - (size_t)r * Q);
-                const mh16 hv = (mh16)(src[idx] * sc);
-                dst[(size_t)r * ldd + q] = hv;
-                if (job == 0) orn_flag_nonfinite(a.sc, (float)hv);      // every element of G passes here once
-            }
-        }
-        return;
-    }
-    // source matrix [R][Q] row-major -> destination rows q (remapped), columns r
-    const float *src; mh16 *dst; int R, Q, ldd; float sc = 1.0f;
-    if (job == 3)      { src = l.g;  dst = l.gt;  R = O; Q = E;      ldd = r16(O); sc = MH_GS; }
-    else if (job == 4) { src = l.w3; dst = l.w3t; R = O; Q = O;      ldd = r16(O); }
-    else               { src = l.w2; dst = l.w2p; R = O; Q = K2 * 9; ldd = r16(O); }
-    const int tq = (Q + 63) / 64;
-    const int r0 = (blk / tq) * 64, q0 = (blk % tq) * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int r = r0 + ty + 4 * i, q = q0 + tx;
-        tile[ty + 4 * i][tx] = (r < R && q < Q) ? src[(size_t)r * Q + q] * sc : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int q = q0 + ty + 4 * i, r = r0 + tx;
-        if (q < Q && r < R) {
-            size_t row = q;
-            if (job == 5) { const int k = q / 9, ij = q - k * 9; row = (size_t)ij * r32(K2) + k; }
-            dst[row * ldd + r] = (mh16)tile[tx][ty + 4 * i];
-        }
-    }
+    int layer, job;
+    const int blk = mh_pack_decode(a, fwd != 0, (int)blockIdx.x, layer, job);
+    mh_pack_block(a, layer, job, blk, tile);
 }
 
 // ---- GEMM ------------------------------------------------------------------------------------------------------
@@ -227,7 +160,7 @@ __global__ void __launch_bounds__(256) k_mgemm_h16(const MhGroup *__restrict__ g
 // ---- host side -------------------------------------------------------------------------------------------------
 struct OrnMergeH16 {
     MhPackAll pack;
-    int pack_blocks;
+    int pack_blocks_grad, pack_blocks_fwd;
     int tiles[2];                 // total 32x32 tiles of the two GEMM launches
 };
 
@@ -252,7 +185,8 @@ int orn_merge_h16_build(void *dev_tables, void *host, int n_layers, const OrnMer
     MhGroup *G = new MhGroup[2]();
     H->pack.n = n_layers;
     H->pack.sc = sc;
-    H->pack.blk_start[0] = 0;
+    H->pack.grad_start[0] = 0;
+    H->pack.fwd_start[0] = 0;
     for (int i = 0; i < n_layers; ++i) {
         const OrnMergeLayer &l = L[i];
         const int C = l.C, O = l.O, E = 9 * C, K2 = 2 * C;
@@ -264,7 +198,10 @@ int orn_merge_h16_build(void *dev_tables, void *host, int n_layers, const OrnMer
         H->pack.l[i] = MhPackLayer{C, O, l.g, l.T, l.w1, l.w2, l.w3, gh, gt, th, w3t, w1h, w2p};
         const int jobs[MH_JOBS] = {orn_cdiv((long)O * E, 256 * MH_CPT), orn_cdiv((long)O * E, 256 * MH_CPT), orn_cdiv((long)K2 * C, 256 * MH_CPT),
                                    orn_cdiv(O, 64) * orn_cdiv(E, 64), orn_cdiv(O, 64) * orn_cdiv(O, 64), orn_cdiv(O, 64) * orn_cdiv(K2 * 9, 64)};
-        for (int j = 0; j < MH_JOBS; ++j) H->pack.blk_start[MH_JOBS * i + j + 1] = H->pack.blk_start[MH_JOBS * i + j] + jobs[j];
+        H->pack.grad_start[2 * i + 1] = H->pack.grad_start[2 * i] + jobs[0];
+        H->pack.grad_start[2 * i + 2] = H->pack.grad_start[2 * i + 1] + jobs[3];
+        const int fj[4] = {jobs[1], jobs[2], jobs[4], jobs[5]};
+        for (int j = 0; j < 4; ++j) H->pack.fwd_start[4 * i + j + 1] = H->pack.fwd_start[4 * i + j] + fj[j];
         MhProb p;
         // dW3[o][m] = (1/GS) sum_e Gh[o][e] Th[m][e]
         p = MhProb{};
@@ -290,7 +227,8 @@ int orn_merge_h16_build(void *dev_tables, void *host, int n_layers, const OrnMer
         p.mode = 0; p.C = l.dw1p; p.scm = C; p.scn = 1; p.bc = (long)K2 * C; p.so = 1.0f / MH_GS;
         mh_add(G[1], p);
     }
-    H->pack_blocks = H->pack.blk_start[MH_JOBS * n_layers];
+    H->pack_blocks_grad = H->pack.grad_start[2 * n_layers];
+    H->pack_blocks_fwd = H->pack.fwd_start[4 * n_layers];
     H->tiles[0] = G[0].tile_start[G[0].n];
     H->tiles[1] = G[1].tile_start[G[1].n];
     hipError_t e = hipMemcpy(dev_tables, G, 2 * sizeof(MhGroup), hipMemcpyHostToDevice);
@@ -299,11 +237,20 @@ int orn_merge_h16_build(void *dev_tables, void *host, int n_layers, const OrnMer
     return 0;
 }
 
-// pack, then {dW3, dT}, then {dW2, dW1 partials}; the slices / dW1 sum stay with orn_launch_merge_bwd_tail_all
+// the forward merge's S launch carries the parameter-side pack jobs: their table and block count for orn_launch_merge_group_linear
+const void *orn_merge_h16_pack(const void *host, int *fwd_blocks)
+{
+    const OrnMergeH16 *H = (const OrnMergeH16 *)host;
+    *fwd_blocks = H->pack_blocks_fwd;
+    return &H->pack;
+}
+
+// (parameter-side pack: forward), gradient-side pack, then {dW3, dT}, then {dW2, dW1 partials}; the slices / dW1 sum stay with
+// orn_launch_merge_bwd_tail_all
 int orn_launch_merge_h16_bwd(const void *dev_tables, const void *host, hipStream_t st)
 {
     const OrnMergeH16 *H = (const OrnMergeH16 *)host;
-    hipLaunchKernelGGL(k_merge_pack, dim3(H->pack_blocks), dim3(256), 0, st, H->pack);
+    hipLaunchKernelGGL(k_merge_pack, dim3(H->pack_blocks_grad), dim3(256), 0, st, H->pack, 0);     // G -> Gh, GT
     ORN_LAUNCH_CHECK("merge_pack");
     const MhGroup *g = (const MhGroup *)dev_tables;
     hipLaunchKernelGGL(k_mgemm_h16, dim3(orn_cdiv(H->tiles[0], 4)), dim3(256), 0, st, g, H->tiles[0]);
