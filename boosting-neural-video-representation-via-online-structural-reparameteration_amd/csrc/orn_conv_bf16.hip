@@ -18,6 +18,7 @@
 // orn_f16: 11-bit significand, same MFMA rate; gradients then travel scaled by 2^20, see the engine).
 #include "orn_internal.h"
 #include <type_traits>
+#include <cstdlib>
 #ifdef ORN_FP16
 #define HNS orn_f16
 typedef _Float16 h16;
@@ -353,6 +354,13 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
     const unsigned b_lane = lds0 + PATCH_LDS + (wn * NB * 32 + l15) * ROWB + 16 * (g4 ^ ((l15 >> 1) & 3));   // weight row + chunk of k-step 0
     const unsigned a_lane = lds0 + (wm * MB * CB_PW + l15) * ROWB;                                         // patch pixel of (row wm*MB, tap 0)
 
+#ifdef ORN_CONV_STAGGER
+    // experiment: phase-shift the CUs of the first round so that patch-load and store bursts do not coincide chip-wide
+    if ((int)blockIdx.x < 256 && blockIdx.y == 0) {
+        const int d = (int)(blockIdx.x % ORN_CONV_STAGGER);
+        for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(32);        // 32 x 64 cycles ~ one tap
+    }
+#endif
     STAMP_RT(0)
     constexpr int NSET = CONV_NSET_DGRAD, LEAD = NSET - 1;   // reads run LEAD k-steps ahead of their MFMAs
     h16x8 fa[NSET][2 * MB], fb[NSET][2 * NB];           // fragment register sets (carried across N tiles by the pipeline)
@@ -909,6 +917,8 @@ int orn_wgrad_bf16_split(int H, int W, int O)
     const int n_ktiles = orn_cdiv(H, WB_TH) * orn_cdiv(W, WB_TW);
     const int per = 3 * orn_cdiv(O, WB_BO);
     int S = (512 / per) / 8 * 8;
+    static const int s_env = getenv("ORN_WGRAD_SMAX") ? atoi(getenv("ORN_WGRAD_SMAX")) : 0;      // tools/probes: split-K sweep
+    if (s_env > 0 && S > s_env) S = s_env;
     // measured at the 720p shapes: below ~2000 K tiles a full wave of work-groups makes the slab write + re-read cost
     // more than the idle CUs do (L3, 900 tiles: 40 slabs beat 56 by 17 us per step)
     if (n_ktiles < 2000 && S > 40) S = 40;

@@ -8,13 +8,17 @@ import orn_amd
 from orn_amd import _lib
 lib = _lib.lib()
 which = (sys.argv[1] if len(sys.argv) > 1 else 'fwd,dgrad,wgrad').split(',')
+half = os.environ.get('ORN_HALF', 'bf16')                 # element type of the buffers / kernel build: bf16 | fp16
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 layer = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 H, W = {4: (360, 640), 3: (180, 320), 2: (90, 160)}[layer]
 C, O, s = 96, 384, 2
 dev = 'cuda'
 torch.manual_seed(0)
-bf = torch.bfloat16
+bf = torch.bfloat16 if half == 'bf16' else torch.float16
+FWD = lib.orn_conv_nhwc_bf16_fwd if half == 'bf16' else lib.orn_conv_nhwc_f16_fwd
+DGRAD = lib.orn_dgrad_nhwc_bf16 if half == 'bf16' else lib.orn_dgrad_nhwc_f16
+WGRAD = lib.orn_wgrad_nhwc_bf16 if half == 'bf16' else lib.orn_wgrad_nhwc_f16
 xpad = torch.zeros(H + 2, W + 2, C, device=dev, dtype=bf)
 xpad[1:-1, 1:-1] = torch.randn(H, W, C, device=dev).to(bf)
 wb = (torch.randn(9, O, C, device=dev) * (1.0 / (9 * C) ** 0.5)).to(bf)
@@ -34,15 +38,15 @@ fl = 2.0 * 9 * C * O * H * W
 
 
 def fwd():
-    _lib.check(lib.orn_conv_nhwc_bf16_fwd(P(xpad), P(wb), _lib.ptr(bp), H, W, C, O, s, P(z), None, st))
+    _lib.check(FWD(P(xpad), P(wb), _lib.ptr(bp), H, W, C, O, s, P(z), None, st))
 
 
 def dgrad():
-    _lib.check(lib.orn_dgrad_nhwc_bf16(P(dypad), P(wd), H, W, O, C, P(zprev), P(dyprev), 2, st))
+    _lib.check(DGRAD(P(dypad), P(wd), H, W, O, C, P(zprev), P(dyprev), 2, st))
 
 
 def wgrad():
-    _lib.check(lib.orn_wgrad_nhwc_bf16(P(xpad), P(dypad), H, W, C, O, s, P(slabs), P(dwf), P(dbf), st))
+    _lib.check(WGRAD(P(xpad), P(dypad), H, W, C, O, s, P(slabs), P(dwf), P(dbf), st))
 
 
 for name in which:
