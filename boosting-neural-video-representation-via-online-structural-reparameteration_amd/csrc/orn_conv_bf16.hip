@@ -354,13 +354,6 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
     const unsigned b_lane = lds0 + PATCH_LDS + (wn * NB * 32 + l15) * ROWB + 16 * (g4 ^ ((l15 >> 1) & 3));   // weight row + chunk of k-step 0
     const unsigned a_lane = lds0 + (wm * MB * CB_PW + l15) * ROWB;                                         // patch pixel of (row wm*MB, tap 0)
 
-#ifdef ORN_CONV_STAGGER
-    // experiment: phase-shift the CUs of the first round so that patch-load and store bursts do not coincide chip-wide
-    if ((int)blockIdx.x < 256 && blockIdx.y == 0) {
-        const int d = (int)(blockIdx.x % ORN_CONV_STAGGER);
-        for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(32);        // 32 x 64 cycles ~ one tap
-    }
-#endif
     STAMP_RT(0)
     constexpr int NSET = CONV_NSET_DGRAD, LEAD = NSET - 1;   // reads run LEAD k-steps ahead of their MFMAs
     h16x8 fa[NSET][2 * MB], fb[NSET][2 * NB];           // fragment register sets (carried across N tiles by the pipeline)

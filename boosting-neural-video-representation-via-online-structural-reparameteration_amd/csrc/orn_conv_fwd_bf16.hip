@@ -308,13 +308,6 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_fwd_nhwc_bf16(Co
 #ifdef ORN_CONV_PRIO
     if (NLOAD != NWAVES && uwave >= NLOAD) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for the non-loader half
 #endif
-#ifdef ORN_CONV_STAGGER
-    // experiment: phase-shift the CUs of the first round so that patch-load and store bursts do not coincide chip-wide
-    if ((int)blockIdx.x < 256 && blockIdx.y == 0) {
-        const int d = (int)(blockIdx.x % ORN_CONV_STAGGER);
-        for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(32);        // 32 x 64 cycles ~ one tap
-    }
-#endif
     STAMP_RT(0)
     constexpr int NSET = EPI_IS_FWD(EPI) ? CONVF_NSET : CONVF_NSET_UNUSED, LEAD = NSET - 1;   // reads run LEAD k-steps ahead of their MFMAs
     h16x8 fa[NSET][MB], fb[NSET][NB];                   // fragment register sets (carried across N tiles by the pipeline)
