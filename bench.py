@@ -38,7 +38,7 @@ CONFIGS = {
 PEAK = {'fp32': 157.3, 'bf16': 2500.0, 'fp16': 2500.0}       # TFLOP/s: fp32 MFMA / dense 16-bit MFMA (MI355X_MICROARCH.md)
 # kernel symbols as rocprofv3 prints them (template arguments: waves M x N, wave tile M x N, epilogue, K chunk, all-taps)
 SYM = {'fwd_last': 'k_conv_fwd_nhwc_bf16<4, 2, 2, 2, 3, 96, false>', 'fwd': 'k_conv_fwd_nhwc_bf16<4, 2, 2, 2, 0, 96, false>',
-       'fwd_narrow': 'k_conv_fwd_nhwc_bf16<4, 2, 2, 2, 0, 32, true>', 'dgrad': 'k_conv_nhwc_bf16<8, 1, 1, 3, 1, 96, false>',
+       'fwd_narrow': 'k_conv_fwd_nhwc_bf16<4, 2, 2, 2, 0, 32, true>', 'dgrad': 'k_dgrad2_nhwc',
        'dgrad_split': 'k_conv_nhwc_bf16<8, 1, 1, 3, 2, 96, false> + k_dgrad_finish',
        'dgrad_narrow': 'k_conv_nhwc_bf16<8, 1, 1, 1, 2, 96, true>', 'wgrad': 'k_wgrad_nhwc_bf16_all',
        'wgrad_reduce': 'k_wgrad_bf16_reduce_all'}

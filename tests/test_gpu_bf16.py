@@ -171,7 +171,8 @@ def test_engine_is_run_to_run_deterministic(orn, prec):
         del eng, gen
         junk = torch.full((64 * 1024 * 1024,), float(rep + 1), device='cuda')
         del junk
-    assert torch.equal(outs[0][2], outs[1][2])
+    rows = [i for i in range(12) if not torch.equal(outs[0][2][i], outs[1][2][i])]
+    assert not rows, ('loss ring rows differ', rows, outs[0][2][rows[0]].tolist(), outs[1][2][rows[0]].tolist())
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1])
 

@@ -33,6 +33,8 @@ slabs = torch.empty(lib.orn_wgrad_nhwc_bf16_ws_bytes(H, W, O) // 4, device=dev)
 dwf = torch.empty(O, C, 3, 3, device=dev)
 dbf = torch.empty(O, device=dev)
 st = _lib.stream()
+if os.environ.get('ORN_DBG'):                             # ablation flags of a -DORN_CONV_ABLATE build
+    lib.orn_debug_set(int(os.environ['ORN_DBG']))
 P = lambda t: c_void_p(t.data_ptr())
 fl = 2.0 * 9 * C * O * H * W
 

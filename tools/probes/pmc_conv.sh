@@ -12,7 +12,7 @@ for d in ('/tmp/pmc_c1', '/tmp/pmc_c2'):
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
             k = r['Kernel_Name']
-            if 'k_conv_nhwc' in k or 'k_conv_fwd' in k or 'k_wgrad' in k:
+            if 'k_conv_nhwc' in k or 'k_conv_fwd' in k or 'k_wgrad' in k or 'k_dgrad2' in k:
                 acc[k[:110]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, cs in acc.items():
     print(k)
