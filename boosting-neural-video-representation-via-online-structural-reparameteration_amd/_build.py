@@ -36,7 +36,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src in _sources():
         s = os.path.join(CSRC, src)
         variants = [('', [])]
-        if src in ('orn_conv_bf16.hip', 'orn_conv_fwd_bf16.hip'):   # the 16-bit fast path is built for bf16 and for IEEE half
+        if src in ('orn_conv_bf16.hip', 'orn_conv_fwd_bf16.hip', 'orn_conv2_bf16.hip'):   # the 16-bit fast path is built for bf16 and for IEEE half
             variants.append(('_f16', ['-DORN_FP16']))
         for suffix, extra in variants:
             o = os.path.join(OBJ, src[:-4] + suffix + '.o')

@@ -509,245 +509,6 @@ __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP
 #undef WAIT_VM
 #undef BARRIER
 
-// ================================================================================================
-// dgrad of the large images (the two biggest launches of the step), second form: TWO work-groups per CU.
-//
-// The form above keeps a 64 KB patch of 96 input channels + a weight ring in LDS: one work-group per CU, and every bubble of that
-// work-group -- the patch load at its start, the exposed patch switch between its four channel chunks, the rendezvous of every tap,
-// the epilogue's z_prev round trip -- idles the matrix pipe (phase stamps: 41 % MFMA busy).  Here the K chunk is 32 channels: a
-// patch is 21 KB, so TWO patches (the next chunk streams in while this one is consumed: no exposed switch) + a 4-deep ring of
-// [96][32] weight tiles are 68 KB, and two 4-wave work-groups share a CU.  Each SIMD then hosts one wave of each work-group:
-// whenever one of them waits -- rendezvous, prologue, epilogue -- the other owns the matrix pipe.
-//   work-group = 8 x 32 output pixels x all 96 output channels; wave w: rows 2w, 2w+1 (wave tile 64 px x 96 ch, 24 accumulator
-//   tiles of v_mfma_f32_16x16x32); K stream = (Cin / 32) chunks x 9 taps, one k-step (24 MFMAs per wave) per (chunk, tap).
-//   Pipeline per step u: fragment reads of u+1 (other register set) | counted lgkmcnt wait for u | counted vmcnt wait + rendezvous
-//   | 24 MFMAs | DMA of weight tile u+4 into the slot of tile u | (taps 0..5) one DMA piece of the NEXT chunk's patch.
-//   What is known to have landed after rendezvous v: weight tiles <= v+2 and the patch pieces issued up to step v-2, because the
-//   wait before rendezvous v leaves exactly the operations issued after rendezvous v-1 in flight (vmcnt counts in issue order).
-// ================================================================================================
-#define D2_CK 32
-#define D2_ROWB 64                                    // LDS bytes per patch pixel / weight row (32 halfs)
-#define D2_PATCH_INSTR ((CB_PH * CB_PW * D2_ROWB + 1023) / 1024)      // 22 DMA wave-instructions per patch
-#define D2_PATCH_LDS (D2_PATCH_INSTR * 1024)
-#define D2_TILE_BYTES (96 * D2_ROWB)                  // 6 DMA wave-instructions per weight tile
-#ifndef D2_NSLOT
-#define D2_NSLOT 4                                     // 5 and 6 (more DMA in flight at every rendezvous) time the same: issue-bound, not latency-bound
-#endif
-#define D2_LDS (2 * D2_PATCH_LDS + D2_NSLOT * D2_TILE_BYTES)
-
-// reads of step (tap TAP) into set SET: 4 pixel sub-blocks (rows 2w + {0,1} + ti, halves) and 6 channel sub-blocks
-// The swizzle term of a patch read, 16 * (g4 ^ ((pix >> 1) & 3)) with pix = 68 w + l15 + 34 r + 16 h + tj (w wave, r patch row
-// relative to the wave's first, h half, tj tap column), only depends on (2 w + r + ((l15 + tj) >> 1)) & 3: eight per-lane values
-// sw[r & 3][x], x = 0 for tj = 0, 1 for tj = 1, and tj = 2 is (r + 1, x = 0).  They are computed once; a read's address is then
-// one add (patch buffer base + term) with the pixel offset in the instruction's immediate.
-template <int SET, int TAP, int I>
-__device__ __forceinline__ void d2_read_a(h16x8 (&fa)[2][4], unsigned a_base, const unsigned (&sw)[4][2])
-{
-    constexpr int ti = TAP / 3, tj = TAP - ti * 3;
-    constexpr int r = (I >> 1) + ti;
-    constexpr unsigned pixoff = r * CB_PW + 16 * (I & 1) + tj;
-    const unsigned addr = a_base + sw[(r + (tj == 2 ? 1 : 0)) & 3][tj == 1 ? 1 : 0];
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[SET][I]) : "v"(addr), "n"(pixoff * D2_ROWB) : "memory");
-}
-template <int SET, int TAP>
-__device__ __forceinline__ void d2_read_step(h16x8 (&fa)[2][4], h16x8 (&fb)[2][6], unsigned a_base, const unsigned (&sw)[4][2], unsigned w_base)
-{
-    d2_read_a<SET, TAP, 0>(fa, a_base, sw);
-    d2_read_a<SET, TAP, 1>(fa, a_base, sw);
-    d2_read_a<SET, TAP, 2>(fa, a_base, sw);
-    d2_read_a<SET, TAP, 3>(fa, a_base, sw);
-    asm volatile("ds_read_b128 %0, %1" : "=v"(fb[SET][0]) : "v"(w_base) : "memory");
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[SET][1]) : "v"(w_base), "n"(16 * D2_ROWB) : "memory");
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[SET][2]) : "v"(w_base), "n"(32 * D2_ROWB) : "memory");
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[SET][3]) : "v"(w_base), "n"(48 * D2_ROWB) : "memory");
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[SET][4]) : "v"(w_base), "n"(64 * D2_ROWB) : "memory");
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[SET][5]) : "v"(w_base), "n"(80 * D2_ROWB) : "memory");
-}
-template <int SET, int PEND>
-__device__ __forceinline__ void d2_wait_set(h16x8 (&fa)[2][4], h16x8 (&fb)[2][6])
-{
-    asm volatile("s_waitcnt lgkmcnt(%10)" : "+v"(fa[SET][0]), "+v"(fa[SET][1]), "+v"(fa[SET][2]), "+v"(fa[SET][3]), "+v"(fb[SET][0]), "+v"(fb[SET][1]),
-                 "+v"(fb[SET][2]), "+v"(fb[SET][3]), "+v"(fb[SET][4]), "+v"(fb[SET][5]) : "n"(PEND));
-}
-template <int SET>
-__device__ __forceinline__ void d2_mfma_step(h16x8 (&fa)[2][4], h16x8 (&fb)[2][6], f32x4 (&acc)[4][6])
-{
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) acc[i][j] = MFMA16_H16(fb[SET][j], fa[SET][i], acc[i][j]);
-}
-// patch pieces (of the next chunk) a wave issues at tap t: all six within the first 7 - LAG taps, so that they are known to have
-// landed at the rendezvous of tap 7, in front of which tap 8 prefetches the next chunk's first fragments
-#define D2_LAG (D2_NSLOT - 3)
-constexpr int d2_npp(int t) { constexpr int n = 7 - D2_LAG; return t >= n ? 0 : (6 / n + (t < 6 % n ? 1 : 0)); }
-constexpr int d2_ppbase(int t) { int b = 0; for (int i = 0; i < t; ++i) b += d2_npp(i); return b; }
-constexpr int d2_inflight(int t) { int n = 0; for (int i = 1; i <= D2_LAG; ++i) n += 2 + d2_npp((t - i + 9) % 9); return n; }
-static_assert(d2_ppbase(9) == 6 && D2_LAG >= 1 && D2_LAG <= 4, "dgrad2: patch piece schedule");
-template <int N> __device__ __forceinline__ void d2_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
-
-__global__ void __launch_bounds__(256, 2) k_dgrad2_nhwc(ConvBP p)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int t = threadIdx.x, lane = t & 63;
-    const int uwave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int l15 = lane & 15, g4 = lane >> 4;
-    const int tile = blockIdx.x;
-    const int tw = tile % p.tiles_w, th = tile / p.tiles_w;
-    const int h0 = th * CB_TH, w0 = tw * CB_TW;
-    const int H = p.H, W = p.W, Cin = p.Cin;
-    const int Q = Cin / D2_CK, U = Q * 9;
-
-    // DMA plans: per-lane SOURCE byte offsets; destination = lane-linear 1 KiB per instruction.  Logical chunk c of row R sits at
-    // position c ^ ((R >> 1) & 3) of its 4-chunk row.  Every wave issues the same operations at every step (patch: 24 issue slots
-    // for 22 instructions, weight tile: 8 for 6 -- the surplus ones load a piece twice; past the end of the stream the loads wrap
-    // around into buffers nobody reads any more), so the counted waits are compile-time constants and the loop has no branches.
-    unsigned p_goff[6], b_goff[2];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const int m = (uwave + 4 * k) % D2_PATCH_INSTR;
-        const int L = m * 64 + lane, pix = L >> 2, pos = L & 3;
-        const int c = pos ^ ((pix >> 1) & 3);
-        const int pr = pix / CB_PW, pc = pix - pr * CB_PW;
-        const int gh = h0 + pr, gw = w0 + pc;
-        const bool ok = (pix < CB_PH * CB_PW) && gh < H + 2 && gw < W + 2;       // others read the all-zero border pixel (0,0)
-        p_goff[k] = (unsigned)((ok ? (gh * (W + 2) + gw) * Cin : 0) + c * 8) * 2u;
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int m = (uwave * 2 + k) % 6;
-        const int L = m * 64 + lane, R = L >> 2, pos = L & 3;
-        b_goff[k] = (unsigned)(R * Cin + (pos ^ ((R >> 1) & 3)) * 8) * 2u;
-    }
-#define D2_DMA16(gptr_, ldsoff_)                                                                                \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr_),                   \
-                                     (__attribute__((address_space(3))) void *)(smem + (ldsoff_)), 16, 0, 0)
-    // one piece (k) of chunk q_'s patch into patch buffer q_ & 1 (chunk Q wraps to chunk 0)
-#define D2_DMA_PATCH_PIECE(qsrc_, buf_, k_)                                                                     \
-    D2_DMA16((const char *)p.xpad + (size_t)(qsrc_) * (D2_CK * 2) + p_goff[k_],                                 \
-             (buf_) * D2_PATCH_LDS + ((uwave + 4 * (k_)) % D2_PATCH_INSTR) * 1024);
-    // weight tile of stream position u_ (chunk u_ / 9, tap u_ % 9; wraps past the end) into ring slot u_ & 3
-#define D2_DMA_TILE_AT(q__, tap__, slot_)                                                                       \
-    {                                                                                                           \
-        const char *wb__ = (const char *)(p.w + ((size_t)(tap__) * 96 * Cin + (size_t)(q__) * D2_CK));          \
-        _Pragma("unroll") for (int k = 0; k < 2; ++k)                                                           \
-            D2_DMA16(wb__ + b_goff[k], 2 * D2_PATCH_LDS + (slot_) * D2_TILE_BYTES + ((uwave * 2 + k) % 6) * 1024); \
-    }
-#define D2_DMA_TILE(u_) D2_DMA_TILE_AT((u_) / 9, (u_) % 9, (u_) % D2_NSLOT)
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
-    const unsigned pix_lane = (2 * uwave) * CB_PW + l15;                                  // patch pixel of (row 2w, column l15)
-    const unsigned a_lane = lds0 + pix_lane * D2_ROWB;
-    const unsigned b_lane = lds0 + 2 * D2_PATCH_LDS + l15 * D2_ROWB + 16 * (g4 ^ ((l15 >> 1) & 3));
-    unsigned sw[4][2];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            sw[r][x] = 16 * (g4 ^ ((2 * uwave + r + ((l15 + x) >> 1)) & 3));
-            asm volatile("" : "+v"(sw[r][x]));
-        }
-
-    f32x4 acc[4][6];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    h16x8 fa[2][4], fb[2][6];
-
-    // prologue: patch of chunk 0, weight tiles 0..R-2, rendezvous; tile R-1 stays in flight behind it
-#pragma unroll
-    for (int k = 0; k < 6; ++k) D2_DMA_PATCH_PIECE(0, 0, k)
-#pragma unroll
-    for (int u0 = 0; u0 < D2_NSLOT - 1; ++u0) D2_DMA_TILE(u0)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    D2_DMA_TILE(D2_NSLOT - 1)
-    d2_read_step<0, 0>(fa, fb, a_lane, sw, b_lane);
-
-    int slot_q = 0;                                      // (9 q) mod R: ring slot of the chunk's first tile
-    for (int q = 0; q < Q; ++q) {
-        const unsigned a_cur_next = a_lane + ((q + 1) & 1) * D2_PATCH_LDS;                 // patch buffer of chunk q + 1
-        const unsigned a_cur = a_lane + (q & 1) * D2_PATCH_LDS;
-        const int q_next = (q + 1 < Q) ? q + 1 : 0;
-        // nine taps: an odd count, so the set that tap 8 prefetched into (set 1) is handed over to set 0 between chunks --
-        // 40 register moves per chunk against 216 MFMAs, and no second copy of the loop body
-        if (q > 0) {
-            d2_wait_set<1, 0>(fa, fb);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[0][i] = fa[1][i];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) fb[0][j] = fb[1][j];
-        }
-        orn_sfor<0, 9>([&](auto tap_c) __attribute__((always_inline)) {
-            constexpr int tap = decltype(tap_c)::value;
-            constexpr int cur = tap & 1, nxt = cur ^ 1;
-            // fragment reads of step u + 1 (its tile is known to have landed since rendezvous u - 1); the reads issued by the
-            // very last step go to wrapped-around data and are never consumed
-            const unsigned wslot = b_lane + ((slot_q + tap + 1) % D2_NSLOT) * D2_TILE_BYTES;
-            if constexpr (tap < 8) d2_read_step<nxt, tap + 1>(fa, fb, a_cur, sw, wslot);
-            else d2_read_step<nxt, 0>(fa, fb, a_cur_next, sw, wslot);
-            d2_wait_set<cur, 10>(fa, fb);
-            // rendezvous u in front of the step's MFMAs.  What has to be known as landed here: weight tile u + 2 (issued at step
-            // u + 2 - R) and, at tap 7, the next chunk's patch: everything issued up to step u - (R - 2).  So the operations of
-            // the LAG = R - 3 steps before this one stay in flight: per step two weight pieces + that step's patch pieces.
-            d2_wait_vm<d2_inflight(tap)>();
-            __builtin_amdgcn_s_barrier();
-            d2_mfma_step<cur>(fa, fb, acc);
-#ifndef D2_ABL_NO_WDMA            // compile-time timing ablations (tools/probes/abl_dgrad2.sh): a runtime flag here splits the tap's
-                                  // basic block and costs 50 us by itself
-            D2_DMA_TILE_AT((tap + D2_NSLOT < 9) ? q : q_next, (tap + D2_NSLOT) % 9, (slot_q + tap) % D2_NSLOT)   // into the slot of tile u: everyone is past its reads
-#endif
-#ifndef D2_ABL_NO_PDMA
-            orn_sfor<0, d2_npp(tap)>([&](auto k_c) __attribute__((always_inline)) {           // next chunk's patch
-                D2_DMA_PATCH_PIECE(q_next, (q + 1) & 1, d2_ppbase(tap) + decltype(k_c)::value)
-            });
-#endif
-        });
-        slot_q = (slot_q + 9) % D2_NSLOT;
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                           // drain the wrapped-around loads before the LDS goes away
-#undef D2_DMA16
-#undef D2_DMA_PATCH_PIECE
-#undef D2_DMA_TILE
-#undef D2_DMA_TILE_AT
-
-    // ---- epilogue: x SiLU'(z_prev), scatter into the previous layer's dypad (see the first form) -------------------
-    const int c8_lane = 16 * (g4 & 1) + 8 * (g4 >> 1);
-#pragma unroll
-    for (int pi = 0; pi < 4; ++pi) {
-        const int gh = h0 + 2 * uwave + (pi >> 1), gw = w0 + 16 * (pi & 1) + l15;
-#ifdef D2_ABL_NO_EPI
-        const bool ok = false;
-#else
-        const bool ok = (gh < H) && (gw < W);
-#endif
-        const int sp = p.sp, ph = conv_div(gh, p.mSp), pw = conv_div(gw, p.mSp);
-        const int sub = (gh - ph * sp) * sp + (gw - pw * sp);
-        h16x8 zz[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            if (ok) zz[j] = *reinterpret_cast<const h16x8 *>(p.zprev + ((size_t)gh * W + gw) * 96 + j * 32 + c8_lane);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int c8 = j * 32 + c8_lane;
-            const f32x4 ta = acc[pi][2 * j], tb = acc[pi][2 * j + 1];
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x0 = ta[e], x1 = tb[e];
-                swap_rows_f(x0, x1);
-                v[e] = x0; v[4 + e] = x1;
-            }
-            if (ok) {
-                h16x8 o8;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o8[e] = (h16)(v[e] * orn_silu_grad((float)zz[j][e]));
-                *reinterpret_cast<h16x8 *>(p.dyprev + ((size_t)(ph + 1) * (W / sp + 2) + (pw + 1)) * (96 * sp * sp) + sub * 96 + c8) = o8;
-            }
-        }
-    }
-}
-
 template <int WAVES_M, int WAVES_N, int MB, int NB, int EPI, int CK = CB_CK, bool ALLTAPS = (CK != CB_CK)>
 static int launch_conv_cfg(const ConvBP &p, int n_tiles_total, hipStream_t st)
 {
@@ -794,6 +555,7 @@ static unsigned conv_magic(int d)
 
 // dgrad: N = 96 in one tile (waves 8x1, wave tile 32 px x 96 ch).  The forward launcher lives with its kernel in
 // orn_conv_fwd_bf16.hip (the other MFMA shape).
+int orn_launch_dgrad2(const h16 *dypad, const h16 *wd, int H, int W, int O, const h16 *zprev, h16 *dyprev, int sp, hipStream_t st);   // orn_conv2_bf16.hip
 int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p, int H, int W, int Cin, int O, int s,
                              h16 *z, h16 *apad, hipStream_t st, int c_real);
 void set_debug_fwd(int flags);
@@ -866,17 +628,7 @@ int orn_launch_conv_bf16_dgrad(const h16 *dypad, const h16 *wd, int H, int W, in
     ORN_REQUIRE(zprev && dyprev && sp >= 1 && H % sp == 0 && W % sp == 0, "conv_bf16_dgrad: bad epilogue arguments");
     static const bool form1 = getenv("ORN_DGRAD_FORM1") != nullptr;       // tools/probes: A/B against the one-work-group-per-CU form
     if (form1) return launch_conv_cfg<8, 1, 1, 3, EPI_B_DGRAD>(p, 1, st);
-    {   // the two-work-groups-per-CU form
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute((const void *)k_dgrad2_nhwc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)D2_LDS);
-            if (e != hipSuccess) { orn_set_error("conv_bf16_dgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-            attr_done = true;
-        }
-        hipLaunchKernelGGL(k_dgrad2_nhwc, dim3(p.tiles_w * p.tiles_h), dim3(256), D2_LDS, st, p);
-        ORN_LAUNCH_CHECK("dgrad2_nhwc");
-        return 0;
-    }
+    return orn_launch_dgrad2(dypad, wd, H, W, O, zprev, dyprev, sp, st);       // two work-groups per CU: orn_conv2_bf16.hip
 }
 
 // ================================================================================================
@@ -1791,7 +1543,7 @@ static Bf16Ws carve_bf16(void *ws, int C, int O, int H, int W, int s)
 extern "C" int HOOK(orn_conv3x3_ps_silu_fwd_bf16, orn_conv3x3_ps_silu_fwd_f16)(const float *x, const float *wf, const float *bf, int C, int O, int H, int W,
                                             int s, float *z, float *a, void *ws, size_t ws_bytes, void *stream)
 {
-    ORN_REQUIRE(x && wf && bf && a && ws, "conv3x3_ps_silu_fwd_bf16: null pointer");
+    ORN_REQUIRE(x && wf && bf && (z || a) && ws, "conv3x3_ps_silu_fwd_bf16: null pointer");   // a == NULL: the last block's form (z only)
     ORN_REQUIRE(C % CB_CK == 0 && O % 32 == 0 && O % (s * s) == 0, "conv3x3_ps_silu_fwd_bf16: unsupported C=%d O=%d s=%d", C, O, s);
     if (ws_bytes < orn_conv3x3_ps_silu_bf16_ws_bytes(C, O, H, W, s)) { orn_set_error("conv3x3_ps_silu_fwd_bf16: workspace too small"); return ORN_E_WS; }
     hipStream_t st = (hipStream_t)stream;
@@ -1799,10 +1551,10 @@ extern "C" int HOOK(orn_conv3x3_ps_silu_fwd_bf16, orn_conv3x3_ps_silu_fwd_f16)(c
     const int Cn = O / (s * s), Hs = H * s, Ws = W * s;
     ORN_TRY(orn_launch_nchw_to_nhwc_pad_bf16(x, C, C, H, W, b.xpad, st));
     ORN_TRY(orn_launch_prep_weights_bf16(wf, bf, O, C, s, b.wb, b.wd, b.biasp, st));
-    ORN_TRY(orn_launch_conv_bf16_fwd(b.xpad, b.wb, b.biasp, H, W, C, O, s, b.zb, b.apad, st, C));
+    ORN_TRY(orn_launch_conv_bf16_fwd(b.xpad, b.wb, b.biasp, H, W, C, O, s, b.zb, a ? b.apad : nullptr, st, C));
     const long n = (long)Cn * Hs * Ws;
     if (z) hipLaunchKernelGGL(k_nhwc_bf16_to_nchw_f32, dim3(orn_cdiv(n, 256)), dim3(256), 0, st, b.zb, Cn, Hs, Ws, 0, z);
-    hipLaunchKernelGGL(k_nhwc_bf16_to_nchw_f32, dim3(orn_cdiv(n, 256)), dim3(256), 0, st, b.apad, Cn, Hs, Ws, 1, a);
+    if (a) hipLaunchKernelGGL(k_nhwc_bf16_to_nchw_f32, dim3(orn_cdiv(n, 256)), dim3(256), 0, st, b.apad, Cn, Hs, Ws, 1, a);
     ORN_LAUNCH_CHECK("nhwc_bf16_to_nchw_f32");
     return 0;
 }

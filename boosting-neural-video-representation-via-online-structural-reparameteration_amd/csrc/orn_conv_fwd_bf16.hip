@@ -519,6 +519,8 @@ static unsigned convf_magic(int d)
     return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned long long)d - 1) / (unsigned long long)d);
 }
 
+int orn_launch_fwd2(const h16 *xpad, const h16 *wb, const float *bias_p, int H, int W, int O, int s, h16 *z, h16 *apad, hipStream_t st);   // orn_conv2_bf16.hip
+
 // fwd: N tile 128 (waves 4x2, wave tile 64 px x 64 ch); dgrad: N = 96 in one tile (waves 8x1, 32 px x 96 ch)
 // c_real: input channels that are not zero padding (<= Cin); <= 32 of them take the narrow form (forward of a non-last block)
 int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p, int H, int W, int Cin, int O, int s,
@@ -548,6 +550,15 @@ int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p
     const float cost_split = (float)orn_cdiv(ptiles * nt_total, 256) * 1.3f;
     p.n_tiles_per_wg = (ptiles >= 512 || cost_whole <= cost_split) ? nt_total : 1;
     if (apad && c_real > 0 && c_real <= 32) return launch_convf_cfg<4, 2, 2, 2, EPI_B_FWD, 32>(p, nt_total, st);
+    // large images with whole 96-channel N tiles: the two-work-groups-per-CU form (orn_conv2_bf16.hip).  Measured in the 720p
+    // step: last block (z only) 150 -> 140 us, but the 180 x 320 block WITH the activation copy 41 -> 54 us (twice the stores
+    // and the SiLU in an epilogue that already spills), so blocks that write `apad` stay here unless ORN_FWD2_APAD is set.
+    static const bool form1 = getenv("ORN_FWD_FORM1") != nullptr;         // tools/probes: A/B against this file's kernel
+    static const bool form2_apad = getenv("ORN_FWD2_APAD") != nullptr;
+    if (!form1 && Cin == 96 && O % 96 == 0 && ptiles >= 128 && (!apad || form2_apad)) {
+        const int rc = orn_launch_fwd2(xpad, wb, bias_p, H, W, O, s, z, apad, st);
+        if (rc != -1) return rc;
+    }
     return apad ? launch_convf_cfg<4, 2, 2, 2, EPI_B_FWD>(p, nt_total, st) : launch_convf_cfg<4, 2, 2, 2, EPI_B_FWD_LAST>(p, nt_total, st);
 }
 

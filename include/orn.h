@@ -87,7 +87,7 @@ ORN_API int orn_conv3x3_ps_silu_bwd(const float *x, const float *wf, const float
  * C % 96 == 0 (bwd: C == 96), O % 128 == 0.  Inputs/outputs stay fp32 NCHW; the channels-last bf16
  * staging (DESIGN.md "data layout") lives in `ws`, which the caller must zero-fill once before the
  * first use (the one-pixel borders are never written).  The engine uses the same kernels without the
- * layout conversions. */
+ * layout conversions.  fwd: `a` may be NULL (the last block's form: z only), then `z` must not be. */
 ORN_API size_t orn_conv3x3_ps_silu_bf16_ws_bytes(int C, int O, int H, int W, int s);
 ORN_API int orn_conv3x3_ps_silu_fwd_bf16(const float *x, const float *wf, const float *bf, int C, int O, int H, int W,
                                  int s, float *z, float *a, void *ws, size_t ws_bytes, void *stream);

@@ -25,7 +25,9 @@ def _half_round(t, half):
 
 @pytest.mark.parametrize('half', ['bf16', 'fp16'])
 @pytest.mark.parametrize('C,O,H,W,s', [(96, 384, 8, 32, 2), (96, 384, 36, 64, 2), (96, 384, 45, 80, 2), (96, 384, 13, 37, 2),
-                                       (96, 1152, 9, 33, 3), (96, 864, 10, 33, 3)])
+                                       (96, 1152, 9, 33, 3), (96, 864, 10, 33, 3),
+                                       # >= 128 pixel tiles: the forward takes the two-work-groups-per-CU form (whole and ragged tiles, s = 2 / 3)
+                                       (96, 384, 64, 512, 2), (96, 384, 67, 500, 2), (96, 864, 66, 480, 3)])
 def test_bf16_block_fwd_bwd(orn, C, O, H, W, s, half):
     """conv3x3+PixelShuffle+SiLU fwd, and dbias / wgrad / dgrad, on 16-bit MFMA -- the bf16 build AND the IEEE-half build
     the engine's fp16 mode (bench.py's headline) launches -- vs the CPU oracle run on the SAME 16-bit-rounded inputs
@@ -56,6 +58,10 @@ def test_bf16_block_fwd_bwd(orn, C, O, H, W, s, half):
     orn._lib.check(fwd_fn(P(xd), P(wd), P(bd), C, O, H, W, s, P(z), P(a), P(ws), c_size_t(nb), st()))
     np.testing.assert_allclose(z.cpu().numpy(), zr.detach().numpy(), rtol=tol, atol=tol)
     np.testing.assert_allclose(a.cpu().numpy(), ar.detach().numpy(), rtol=tol, atol=tol)
+    # the last block's form (no activation copy): on >= 128 pixel tiles this is the two-work-groups-per-CU kernel
+    z2 = torch.full_like(z, float('nan'))
+    orn._lib.check(fwd_fn(P(xd), P(wd), P(bd), C, O, H, W, s, P(z2), None, P(ws), c_size_t(nb), st()))
+    np.testing.assert_allclose(z2.cpu().numpy(), zr.detach().numpy(), rtol=tol, atol=tol)
     if C != 96:
         return
     # backward with the oracle's z and the same bf16-rounded dy the kernel sees
