@@ -8,11 +8,13 @@
 // 32 channels: a patch is 21 KB, so TWO patches (the next chunk streams in while this one is consumed: no exposed switch) + a
 // 4-deep ring of [96][32] weight tiles are 68 KB, and two 4-wave work-groups share a CU.  Each SIMD then hosts one wave of each
 // work-group: whenever one of them waits -- rendezvous, prologue, epilogue -- the other owns the matrix pipe.
-//   work-group = 8 x 32 output pixels x 96 output channels per segment; wave w: rows 2w, 2w+1 (wave tile 64 px x 96 ch, 24
-//   accumulator tiles); K stream of a segment = chunks x 9 taps, one k-step (24 MFMAs per wave) per (chunk, tap).
-//     dgrad:   one segment of Cin / 32 chunks (Cin = the layer's conv output channels), epilogue at the end;
-//     forward: a segment = one 96-channel N tile = 3 chunks (K = 9 x 96), epilogue after each; a work-group runs `nseg` of them
-//              back to back -- the DMA stream and the fragment prefetch run on across segment ends.
+//   work-group = 8 x 32 output pixels x 96 output channels; wave w: rows 2w, 2w+1 (wave tile 64 px x 96 ch, 24 accumulator
+//   tiles); K stream = chunks x 9 taps, one k-step (24 MFMAs per wave) per (chunk, tap), epilogue at the end.
+//     dgrad:   Cin / 32 chunks (Cin = the layer's conv output channels);
+//     forward: one 96-channel N tile = 3 chunks (K = 9 x 96) per work-group; the O / 96 work-groups of a pixel tile follow each
+//              other on one XCD.  With 96 channels per output pixel (Cn == 96) an N tile is ALL channels of one output
+//              sub-position, so the last block's epilogue CAN also run the A5 head (1x1 conv 96 -> 3 + activation) on them
+//              (ORN_HEAD_FUSED=1; measured slower than the separate HBM-bound head kernel, see orn_launch_fwd2).
 //   Pipeline per step u: fragment reads of u+1 (other register set) | counted lgkmcnt wait for u | counted vmcnt wait + rendezvous
 //   | 24 MFMAs | DMA of weight tile u+4 into the slot of tile u | (taps 0..5) one DMA piece of the NEXT chunk's patch.
 //   What is known to have landed after rendezvous v: weight tiles <= v+2 and the patch pieces issued up to step v-2, because the
@@ -69,8 +71,8 @@ struct Conv2P {
     const h16 *w;        // forward: [9][Nout][96]; dgrad: [9][96][Cx]
     int H, W, Cx;
     int wrow, wtap;      // elements between two weight rows / BYTES between two taps
-    int qseg, nseg;      // chunks of 32 channels per segment, segments per work-group
-    int tiles_w, tiles_h, ptiles, nsplit;   // forward: `nsplit` work-groups share a pixel tile (nseg N tiles each)
+    int qseg;            // chunks of 32 channels per work-group
+    int tiles_w, tiles_h, ptiles, nsplit;   // forward: `nsplit` = O / 96 work-groups share a pixel tile, one N tile each
     // dgrad epilogue
     const h16 *zprev;    // [H][W][96]
     h16 *dyprev;         // [H/sp+2][W/sp+2][96*sp*sp]
@@ -83,6 +85,10 @@ struct Conv2P {
     int s, Cn, Nout;
     unsigned z_bytes, apad_bytes;   // sizes of the two buffers (raw-buffer bounds)
     unsigned mCn, mS;
+    // A5 head in the last block's epilogue (C2_FWD_LAST, Cn == 96: an N tile is all channels of one output sub-position)
+    const float *head_w, *head_b;   // [3][96], [3]
+    float *head_out;                // fp32 [3][H*s][W*s], or null: no head
+    int head_sigmoid;
 };
 
 __device__ __forceinline__ int c2_div(int x, unsigned m) { return m ? (int)__umulhi((unsigned)x, m) : x; }
@@ -185,12 +191,12 @@ __global__ void __launch_bounds__(256, 2) k_conv2_nhwc(Conv2P p)
         const int ns = r % p.nsplit;
         tile = (r / p.nsplit) * 8 + xcd;
         if (tile >= p.ptiles) return;
-        seg0 = ns * p.nseg;
+        seg0 = ns;
     }
     const int tw = tile % p.tiles_w, th = tile / p.tiles_w;
     const int h0 = th * C2_TH, w0 = tw * C2_TW;
     const int H = p.H, W = p.W, Cx = p.Cx;
-    const int QS = p.qseg, NSEG = p.nseg, NCHUNK = QS * NSEG;
+    const int QS = p.qseg;
 
     // DMA plans: per-lane SOURCE byte offsets; destination = lane-linear 1 KiB per instruction.  Every wave issues the same
     // operations at every step (patch: 24 issue slots for 22 instructions, weight tile: 8 for 6 -- the surplus ones load a piece
@@ -241,7 +247,11 @@ __global__ void __launch_bounds__(256, 2) k_conv2_nhwc(Conv2P p)
     // forward: this work-group's biases behind the ring
     float *sbias = reinterpret_cast<float *>(smem + C2_LDS);
     if (EPI != C2_DGRAD)
-        for (int i = t; i < NSEG * 96; i += 256) sbias[i] = p.bias ? p.bias[seg0 * 96 + i] : 0.f;
+        for (int i = t; i < 96; i += 256) sbias[i] = p.bias ? p.bias[seg0 * 96 + i] : 0.f;
+    float *shead = sbias + 96;                    // [3][96] head weights + [3] biases (+ pad)
+    const bool head = (EPI == C2_FWD_LAST) && p.head_out != nullptr;
+    if (EPI == C2_FWD_LAST && head)
+        for (int i = t; i < 3 * 96 + 3; i += 256) shead[i] = i < 3 * 96 ? p.head_w[i] : p.head_b[i - 3 * 96];
     // z / apad as raw buffers: a byte offset of 0x80000000 (out of range for any buffer the launcher admits) drops the lane's
     // store, so every lane issues every store and the number of vector-memory operations of an epilogue is a constant
     const auto z_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.z, 0, EPI != C2_DGRAD ? p.z_bytes : 0, 0x00020000);
@@ -266,12 +276,10 @@ __global__ void __launch_bounds__(256, 2) k_conv2_nhwc(Conv2P p)
     C2_DMA_TILE_AT(w_cur, C2_NSLOT - 1, C2_NSLOT - 1)
     c2_read_step<0, 0>(fa, fb, a_lane, sw, b_lane);
 
-    int q = 0, seg = 0;
     int slot_c = 0;                                      // (9 c) mod R: ring slot of the chunk's first tile
-    for (int c = 0; c < NCHUNK; ++c) {
-        int qn = q + 1, segn = seg;                      // the chunk after this one (past the end: wraps to the first, never consumed)
-        if (qn == QS) { qn = 0; segn = (seg + 1 < NSEG) ? seg + 1 : 0; }
-        const h16 *w_nxt = p.w + (size_t)(seg0 + segn) * 96 * p.wrow + qn * C2_CK;
+    for (int c = 0; c < QS; ++c) {
+        const int qn = (c + 1 < QS) ? c + 1 : 0;         // the chunk after this one (past the end: wraps to the first, never consumed)
+        const h16 *w_nxt = p.w + (size_t)seg0 * 96 * p.wrow + qn * C2_CK;
         const unsigned a_cur = a_lane + (c & 1) * C2_PATCH_LDS;
         const unsigned a_nxt = a_lane + ((c + 1) & 1) * C2_PATCH_LDS;
         // nine taps: an odd count, so the set that tap 8 prefetched into (set 1) is handed over to set 0 between chunks --
@@ -310,58 +318,95 @@ __global__ void __launch_bounds__(256, 2) k_conv2_nhwc(Conv2P p)
         });
         slot_c = (slot_c + 9) % C2_NSLOT;
 
-        if (EPI != C2_DGRAD && q == QS - 1) {
-            // ---- forward epilogue of segment `seg`: + bias, PixelShuffle scatter of z (and of a = SiLU(z) into the next block's
-            // padded input), 8 channels = 16 B per lane and store -------------------------------------------------------------
-            // The fragments tap 8 prefetched (set 1) are still being written by the LDS as far as the compiler knows nothing of:
-            // retire them first, so that a spill or copy of those registers around this register-hungry block moves real data
-            // (they were issued 24 MFMAs ago: the wait is free).
-            c2_wait_set<1, 0>(fa, fb);
-            const int n0 = (seg0 + seg) * 96;
-#pragma unroll
-            for (int pi = 0; pi < 4; ++pi) {
-                const int gh = h0 + 2 * uwave + (pi >> 1), gw = w0 + 16 * (pi & 1) + l15;
-                const bool ok = (gh < H) && (gw < W);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int c8 = n0 + j * 32 + c8_lane;
-                    const float4 ba = *reinterpret_cast<const float4 *>(sbias + seg * 96 + j * 32 + c8_lane);
-                    const float4 bb = *reinterpret_cast<const float4 *>(sbias + seg * 96 + j * 32 + c8_lane + 4);
-                    const f32x4 ta = acc[pi][2 * j], tb = acc[pi][2 * j + 1];
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float x0 = ta[e], x1 = tb[e];
-                        c2_swap_rows_f(x0, x1);
-                        v[e] = x0; v[4 + e] = x1;
-                    }
-                    v[0] += ba.x; v[1] += ba.y; v[2] += ba.z; v[3] += ba.w;
-                    v[4] += bb.x; v[5] += bb.y; v[6] += bb.z; v[7] += bb.w;
-                    const int ij = c2_div(c8, p.mCn), n = c8 - ij * p.Cn;
-                    const int si = c2_div(ij, p.mS), sj = ij - si * p.s;
-                    const int Ws = W * p.s, oh = gh * p.s + si, ow = gw * p.s + sj;
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{c2_pack(v[0], v[1]), c2_pack(v[2], v[3]), c2_pack(v[4], v[5]), c2_pack(v[6], v[7])}, z_rsrc,
-                                                           ok ? ((oh * Ws + ow) * p.Cn + n) * 2 : (int)0x80000000, 0, 0);   // < 2^31 bytes: launcher
-                    if (EPI == C2_FWD) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = orn_silu(v[e]);
-                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{c2_pack(v[0], v[1]), c2_pack(v[2], v[3]), c2_pack(v[4], v[5]), c2_pack(v[6], v[7])}, a_rsrc,
-                                                               ok ? (((oh + 1) * (Ws + 2) + (ow + 1)) * p.Cn + n) * 2 : (int)0x80000000, 0, 0);
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        q = qn; seg = segn; w_cur = w_nxt;
+        w_cur = w_nxt;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                           // drain the wrapped-around loads before the LDS goes away
 #undef C2_DMA16
 #undef C2_DMA_PATCH_PIECE
 #undef C2_DMA_TILE_AT
 
+    if (EPI != C2_DGRAD) {
+        // ---- forward epilogue: + bias, PixelShuffle scatter of z (and of a = SiLU(z) into the next block's
+        // padded input), 8 channels = 16 B per lane and store -------------------------------------------------------------
+        const int n0 = seg0 * 96;
+        float hu[4][3];                               // head: this lane's partial W . SiLU(z) of its 4 pixels
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi) hu[pi][0] = hu[pi][1] = hu[pi][2] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int c8 = n0 + j * 32 + c8_lane;
+            const float4 ba = *reinterpret_cast<const float4 *>(sbias + j * 32 + c8_lane);
+            const float4 bb = *reinterpret_cast<const float4 *>(sbias + j * 32 + c8_lane + 4);
+            const int ij = c2_div(c8, p.mCn), n = c8 - ij * p.Cn;
+            const int si = c2_div(ij, p.mS), sj = ij - si * p.s;
+            float hw[3][8];
+            if (EPI == C2_FWD_LAST && head) {
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    const float4 w0 = *reinterpret_cast<const float4 *>(shead + o * 96 + j * 32 + c8_lane);
+                    const float4 w1 = *reinterpret_cast<const float4 *>(shead + o * 96 + j * 32 + c8_lane + 4);
+                    hw[o][0] = w0.x; hw[o][1] = w0.y; hw[o][2] = w0.z; hw[o][3] = w0.w;
+                    hw[o][4] = w1.x; hw[o][5] = w1.y; hw[o][6] = w1.z; hw[o][7] = w1.w;
+                }
+            }
+#pragma unroll
+            for (int pi = 0; pi < 4; ++pi) {
+                const int gh = h0 + 2 * uwave + (pi >> 1), gw = w0 + 16 * (pi & 1) + l15;
+                const bool ok = (gh < H) && (gw < W);
+                const f32x4 ta = acc[pi][2 * j], tb = acc[pi][2 * j + 1];
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x0 = ta[e], x1 = tb[e];
+                    c2_swap_rows_f(x0, x1);
+                    v[e] = x0; v[4 + e] = x1;
+                }
+                v[0] += ba.x; v[1] += ba.y; v[2] += ba.z; v[3] += ba.w;
+                v[4] += bb.x; v[5] += bb.y; v[6] += bb.z; v[7] += bb.w;
+                const int Ws = W * p.s, oh = gh * p.s + si, ow = gw * p.s + sj;
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{c2_pack(v[0], v[1]), c2_pack(v[2], v[3]), c2_pack(v[4], v[5]), c2_pack(v[6], v[7])}, z_rsrc,
+                                                       ok ? ((oh * Ws + ow) * p.Cn + n) * 2 : (int)0x80000000, 0, 0);   // < 2^31 bytes: launcher
+                if (EPI == C2_FWD) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = orn_silu(v[e]);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{c2_pack(v[0], v[1]), c2_pack(v[2], v[3]), c2_pack(v[4], v[5]), c2_pack(v[6], v[7])}, a_rsrc,
+                                                           ok ? (((oh + 1) * (Ws + 2) + (ow + 1)) * p.Cn + n) * 2 : (int)0x80000000, 0, 0);
+                }
+                if (EPI == C2_FWD_LAST && head) {
+                    // on the 16-bit z that was just stored: what the separate head kernel reads back, and what the backward uses
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float a = orn_silu((float)(h16)v[e]);
+                        hu[pi][0] = fmaf(hw[0][e], a, hu[pi][0]);
+                        hu[pi][1] = fmaf(hw[1][e], a, hu[pi][1]);
+                        hu[pi][2] = fmaf(hw[2][e], a, hu[pi][2]);
+                    }
+                }
+            }
+        }
+        if (EPI == C2_FWD_LAST && head) {
+            // the four lanes l15 + 16 g of a pixel hold 24 channels each: sum them, lane g < 3 stores output channel g
+            const int ij = c2_div(n0, p.mCn), si = c2_div(ij, p.mS), sj = ij - si * p.s;
+            const size_t HWs = (size_t)(H * p.s) * (W * p.s);
+#pragma unroll
+            for (int pi = 0; pi < 4; ++pi) {
+                const int gh = h0 + 2 * uwave + (pi >> 1), gw = w0 + 16 * (pi & 1) + l15;
+                float u = 0.f;
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    float x = hu[pi][o];
+                    x += __shfl_xor(x, 16, 64);
+                    x += __shfl_xor(x, 32, 64);
+                    if (g4 == o) u = x;
+                }
+                if (g4 < 3 && gh < H && gw < W) {
+                    u += shead[3 * 96 + g4];
+                    const int oh = gh * p.s + si, ow = gw * p.s + sj;
+                    p.head_out[(size_t)g4 * HWs + (size_t)oh * (W * p.s) + ow] = p.head_sigmoid ? 1.0f / (1.0f + __expf(-u)) : (tanhf(u) + 1.0f) * 0.5f;
+                }
+            }
+        }
+    }
     if (EPI == C2_DGRAD) {
         // ---- dgrad epilogue: x SiLU'(z_prev), scatter into the previous block's padded gradient -----------------------------
 #pragma unroll
@@ -402,7 +447,7 @@ static int c2_launch(const Conv2P &p, int blocks, size_t lds, hipStream_t st, co
     // (one process drives one device: the attribute is set once per process, see include/orn.h)
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_conv2_nhwc<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C2_LDS + 8192));
+        hipError_t e = hipFuncSetAttribute((const void *)k_conv2_nhwc<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C2_LDS + 2048));
         if (e != hipSuccess) { orn_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
@@ -420,7 +465,7 @@ int orn_launch_dgrad2(const h16 *dypad, const h16 *wd, int H, int W, int O, cons
     Conv2P p = {};
     p.xpad = dypad; p.w = wd; p.H = H; p.W = W; p.Cx = O;
     p.wrow = O; p.wtap = 96 * O * 2;                      // (wtap in BYTES)
-    p.qseg = O / C2_CK; p.nseg = 1;
+    p.qseg = O / C2_CK;
     p.tiles_w = orn_cdiv(W, C2_TW); p.tiles_h = orn_cdiv(H, C2_TH); p.ptiles = p.tiles_w * p.tiles_h; p.nsplit = 1;
     p.zprev = zprev; p.dyprev = dyprev; p.sp = sp; p.mSp = c2_magic(sp);
     return c2_launch<C2_DGRAD>(p, p.ptiles, C2_LDS, st, "dgrad2_nhwc");
@@ -428,7 +473,7 @@ int orn_launch_dgrad2(const h16 *dypad, const h16 *wd, int H, int W, int O, cons
 
 // forward of a block with 96 input channels and O % 96 == 0 output channels.  Returns -1 without launching when the shape is
 // not this form's (the caller falls back to the first form).
-int orn_launch_fwd2(const h16 *xpad, const h16 *wb, const float *bias_p, int H, int W, int O, int s, h16 *z, h16 *apad, hipStream_t st)
+int orn_launch_fwd2(const h16 *xpad, const h16 *wb, const float *bias_p, int H, int W, int O, int s, h16 *z, h16 *apad, hipStream_t st, OrnHeadFuse *head)
 {
     if (O % 96 != 0 || O > 2048) return -1;
     Conv2P p = {};
@@ -437,18 +482,24 @@ int orn_launch_fwd2(const h16 *xpad, const h16 *wb, const float *bias_p, int H, 
     p.qseg = 3;
     p.tiles_w = orn_cdiv(W, C2_TW); p.tiles_h = orn_cdiv(H, C2_TH); p.ptiles = p.tiles_w * p.tiles_h;
     const int NT = O / 96;
-    // One work-group per (pixel tile, N tile): an epilogue's stores then never sit in front of a later rendezvous' counted wait
-    // (L4 at 720p: nsplit 1 / 2 / 4 = 160 / 162 / 154 us).  ORN_FWD2_NSPLIT (tools/probes) runs NT / nsplit N tiles per work-group.
-    static const int env_split = getenv("ORN_FWD2_NSPLIT") ? atoi(getenv("ORN_FWD2_NSPLIT")) : 0;
-    int nsplit = NT;
-    if (env_split > 0 && NT % env_split == 0) nsplit = env_split;
-    p.nsplit = nsplit; p.nseg = NT / nsplit;
+    // One work-group per (pixel tile, N tile).  (Several N tiles per work-group, the epilogue inside the loop and the streams
+    // running on across it, measured 160 / 162 us at 1 / 2 work-groups per tile against 154 us: an epilogue's stores sit in
+    // front of the next rendezvous' counted wait, and its registers spill into the tap loop.)
+    p.nsplit = NT;
     p.bias = bias_p; p.z = z; p.apad = apad; p.s = s; p.Cn = O / (s * s); p.Nout = O;
     p.z_bytes = (unsigned)((size_t)(H * s) * (W * s) * p.Cn * 2);
     p.apad_bytes = apad ? (unsigned)((size_t)(H * s + 2) * (W * s + 2) * p.Cn * 2) : 0;
     p.mCn = c2_magic(p.Cn); p.mS = c2_magic(s);
-    const int blocks = orn_cdiv(p.ptiles, 8) * 8 * nsplit;
-    const size_t lds = C2_LDS + (size_t)p.nseg * 96 * 4;
+    // The head in this epilogue is correct (tests run it with ORN_HEAD_FUSED=1) but does not pay: 96 SiLUs + 288 FMAs per lane on
+    // the vector pipe cost the last block 145 -> 190 us, the 42 us HBM-bound head kernel it replaces included -- and the denser
+    // launch drags the clock of its neighbours down (720p step 1.168 -> 1.188 ms on one box).  Off unless asked for.
+    static const bool fuse_head = getenv("ORN_HEAD_FUSED") != nullptr;
+    if (head && !apad && p.Cn == 96 && fuse_head) {
+        p.head_w = head->w; p.head_b = head->b; p.head_out = head->out; p.head_sigmoid = head->sigmoid;
+        head->fused = 1;
+    }
+    const int blocks = orn_cdiv(p.ptiles, 8) * 8 * p.nsplit;
+    const size_t lds = C2_LDS + 96 * 4 + (p.head_out ? (3 * 96 + 4) * 4 : 0);
     return apad ? c2_launch<C2_FWD>(p, blocks, lds, st, "fwd2_nhwc") : c2_launch<C2_FWD_LAST>(p, blocks, lds, st, "fwd2_nhwc_last");
 }
 

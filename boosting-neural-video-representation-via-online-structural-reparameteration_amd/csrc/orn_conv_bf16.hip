@@ -557,7 +557,7 @@ static unsigned conv_magic(int d)
 // orn_conv_fwd_bf16.hip (the other MFMA shape).
 int orn_launch_dgrad2(const h16 *dypad, const h16 *wd, int H, int W, int O, const h16 *zprev, h16 *dyprev, int sp, hipStream_t st);   // orn_conv2_bf16.hip
 int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p, int H, int W, int Cin, int O, int s,
-                             h16 *z, h16 *apad, hipStream_t st, int c_real);
+                             h16 *z, h16 *apad, hipStream_t st, int c_real, OrnHeadFuse *head = nullptr);
 void set_debug_fwd(int flags);
 #ifdef ORN_CONV_STAMP
 void set_stamps_fwd(void *buf);
@@ -1432,8 +1432,8 @@ int orn_launch_head_bwd_bf16(const h16 *z, const float *w, const float *out, con
 
 // ---- type-erased operation table for the engine (one per compiled element type) -----------------------
 static int a_conv_fwd(const void *xpad, const void *wb, const float *bias_p, int H, int W, int Cin, int O, int s, void *z, void *apad,
-                      hipStream_t st, int c_real)
-{ return orn_launch_conv_bf16_fwd((const h16 *)xpad, (const h16 *)wb, bias_p, H, W, Cin, O, s, (h16 *)z, (h16 *)apad, st, c_real); }
+                      hipStream_t st, int c_real, OrnHeadFuse *head)
+{ return orn_launch_conv_bf16_fwd((const h16 *)xpad, (const h16 *)wb, bias_p, H, W, Cin, O, s, (h16 *)z, (h16 *)apad, st, c_real, head); }
 static int a_conv_dgrad(const void *dypad, const void *wd, int H, int W, int O, int C, const void *zprev, void *dyprev, int sp,
                         float *dx_f32, hipStream_t st, int c_real)
 { return orn_launch_conv_bf16_dgrad((const h16 *)dypad, (const h16 *)wd, H, W, O, C, (const h16 *)zprev, (h16 *)dyprev, sp, dx_f32, st, c_real); }

@@ -519,12 +519,12 @@ static unsigned convf_magic(int d)
     return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned long long)d - 1) / (unsigned long long)d);
 }
 
-int orn_launch_fwd2(const h16 *xpad, const h16 *wb, const float *bias_p, int H, int W, int O, int s, h16 *z, h16 *apad, hipStream_t st);   // orn_conv2_bf16.hip
+int orn_launch_fwd2(const h16 *xpad, const h16 *wb, const float *bias_p, int H, int W, int O, int s, h16 *z, h16 *apad, hipStream_t st, OrnHeadFuse *head);   // orn_conv2_bf16.hip
 
 // fwd: N tile 128 (waves 4x2, wave tile 64 px x 64 ch); dgrad: N = 96 in one tile (waves 8x1, 32 px x 96 ch)
 // c_real: input channels that are not zero padding (<= Cin); <= 32 of them take the narrow form (forward of a non-last block)
 int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p, int H, int W, int Cin, int O, int s,
-                             h16 *z, h16 *apad, hipStream_t st, int c_real)
+                             h16 *z, h16 *apad, hipStream_t st, int c_real, OrnHeadFuse *head)
 {
     // O % 32: whole MFMA blocks; an O that is not a multiple of the 128-channel N tile gets a ragged last tile whose weight
     // DMA reads up to 96 rows past row O of each tap: `wb` must be readable for 96 * Cin elements behind its last row
@@ -556,7 +556,7 @@ int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p
     static const bool form1 = getenv("ORN_FWD_FORM1") != nullptr;         // tools/probes: A/B against this file's kernel
     static const bool form2_apad = getenv("ORN_FWD2_APAD") != nullptr;
     if (!form1 && Cin == 96 && O % 96 == 0 && ptiles >= 128 && (!apad || form2_apad)) {
-        const int rc = orn_launch_fwd2(xpad, wb, bias_p, H, W, O, s, z, apad, st);
+        const int rc = orn_launch_fwd2(xpad, wb, bias_p, H, W, O, s, z, apad, st, head);
         if (rc != -1) return rc;
     }
     return apad ? launch_convf_cfg<4, 2, 2, 2, EPI_B_FWD>(p, nt_total, st) : launch_convf_cfg<4, 2, 2, 2, EPI_B_FWD_LAST>(p, nt_total, st);

@@ -406,6 +406,7 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
         }
         ORN_TRY(e->ops->prep_all(nl - ff, pl, st));
     }
+    OrnHeadFuse hf = {};
     for (int i = 0; i < nl; ++i) {
         const orn_layer_desc &l = d.layer[i];
         LayerBuf &b = e->L[i];
@@ -421,13 +422,18 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
         } else {
             if (i == ff && !e->stage0) ORN_TRY(e->ops->to_nhwc(x, l.C, ORN_FAST_C, l.H, l.W, b.xpad, st));
             if (e->prof) (void)hipEventRecord(e->prof_ev[2 * i], st);
-            ORN_TRY(e->ops->conv_fwd(b.xpad, b.wb, b.biasp, l.H, l.W, ORN_FAST_C, l.O, l.s, b.zb, (i + 1 < nl) ? e->L[i + 1].xpad : nullptr, st, l.C));
+            // the last block's kernel may run the head in its epilogue (it then holds every channel of an output pixel)
+            const bool last = (i + 1 == nl);
+            if (last) hf = OrnHeadFuse{P + d.head_w, P + d.head_b, e->img, d.sigmoid, 0};
+            ORN_TRY(e->ops->conv_fwd(b.xpad, b.wb, b.biasp, l.H, l.W, ORN_FAST_C, l.O, l.s, b.zb, last ? nullptr : e->L[i + 1].xpad, st, l.C,
+                                     last ? &hf : nullptr));
             if (e->prof) (void)hipEventRecord(e->prof_ev[2 * i + 1], st);
         }
     }
-    if (ff < nl)
-        ORN_TRY(e->ops->head_fwd(e->L[nl - 1].zb, P + d.head_w, P + d.head_b, e->Cn_last, (size_t)e->Hout * e->Wout, d.sigmoid, e->img, st));
-    else
+    if (ff < nl) {
+        if (!hf.fused)
+            ORN_TRY(e->ops->head_fwd(e->L[nl - 1].zb, P + d.head_w, P + d.head_b, e->Cn_last, (size_t)e->Hout * e->Wout, d.sigmoid, e->img, st));
+    } else
         ORN_TRY(orn_launch_head_fwd(x, P + d.head_w, P + d.head_b, 1, e->Cn_last, (size_t)e->Hout * e->Wout, d.sigmoid, e->img, st));
     return 0;
 }

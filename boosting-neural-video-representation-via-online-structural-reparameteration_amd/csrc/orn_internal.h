@@ -99,9 +99,12 @@ struct OrnWgradReduce { const float *slabs; int H, W, C, O, s; float gscale; flo
 // deferred reduction of the 16-bit head backward's per-block partials (head_bwd called with dw == nullptr leaves them in ws)
 struct OrnHeadFinish { const float *partial; int blocks, C; float gscale; float *dw, *db; OrnScaleState *sc; };
 struct OrnWgradJob { const void *xpad, *dypad; int H, W, C, O, s; float *slabs; };   // wgrad into slabs, reduction deferred
+// A5 head riding on the last block's forward (its epilogue holds all channels of an output pixel): out = act(W SiLU(z) + b).
+// The launcher sets `fused` when the kernel it chose did the head; otherwise the caller launches head_fwd on z.
+struct OrnHeadFuse { const float *w, *b; float *out; int sigmoid; int fused; };
 struct OrnHalfOps {
     int (*conv_fwd)(const void *xpad, const void *wb, const float *bias_p, int H, int W, int Cin, int O, int s, void *z, void *apad,
-                    hipStream_t st, int c_real);   // c_real <= Cin: input channels that are not zero padding
+                    hipStream_t st, int c_real, OrnHeadFuse *head);   // c_real <= Cin: input channels that are not zero padding; head: optional
     int (*conv_dgrad)(const void *dypad, const void *wd, int H, int W, int O, int C, const void *zprev, void *dyprev, int sp,
                       float *dx_f32, hipStream_t st, int c_real);   // c_real: output channels that are not zero padding
     size_t (*wgrad_ws_floats)(int H, int W, int O);
