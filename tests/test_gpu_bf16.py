@@ -2,6 +2,7 @@
 fp32 oracle.  Tolerances are bf16 tolerances: inputs/weights rounded to 8 significant bits, fp32
 accumulation; stated per assertion."""
 import math
+import os
 from ctypes import c_size_t
 
 import numpy as np
@@ -154,6 +155,20 @@ def test_bf16_engine_720p_decode_and_step(orn, half, cfg):
     assert torch.isfinite(sb).all() and abs(sb[0] - sf[0]) <= 2e-3 * abs(sf[0])
     worst = max((_rel(gb[k], gf[k]), k) for k in gf if gf[k].norm() > 0)
     assert worst[0] < (1e-2 if half == 'fp16' else 5e-2), worst
+
+
+@pytest.mark.parametrize('switch', ['ORN_HEAD_FUSED', 'ORN_FWD2_APAD', 'ORN_FWD_FORM1', 'ORN_DGRAD_FORM1'])
+def test_kernel_selection_switches_keep_the_720p_step_correct(switch):
+    """The launchers pick between kernel forms by shape; the forms that are NOT the default at 720p stay selectable through
+    environment switches read once per process (tools/probes A/B runs): the head inside the last block's epilogue, the
+    two-work-groups-per-CU forward for blocks that also write the activation copy, and the first forms of forward and dgrad.
+    Each must pass the 720p engine-vs-fp32 check of this file in a process of its own."""
+    import subprocess
+    import sys
+    env = dict(os.environ, **{switch: '1'})
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-m', 'gpu', '-x', '-p', 'no:cacheprovider',
+                        '-k', 'test_bf16_engine_720p_decode_and_step and fp16-720p'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and '1 passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize('prec', ['fp32', 'bf16', 'fp16'])
