@@ -18,6 +18,14 @@
  *     > 0 = hipError_t of a failed launch.  Nothing throws across the ABI, nothing calls exit().
  *   - All reductions are fixed-order two-pass trees: results are run-to-run bit-identical.
  *   - `ws` arguments are scratch; the required size comes from the matching *_ws_bytes().
+ *   - One process drives ONE device (the deployment model of this path: one rank per GPU).  Kernels that need more than 64 KB
+ *     of LDS raise their limit with hipFuncSetAttribute the first time they are launched and remember that in a process-wide
+ *     flag; the attribute is per device, so a process that switches devices after its first call must not use this library
+ *     on the second device.  Entry points may be called from several host threads as long as they use the same device
+ *     (setting the attribute twice is harmless); orn_last_error is per thread.
+ *   - Environment switches ORN_FWD_FORM1, ORN_DGRAD_FORM1, ORN_FWD2_APAD, ORN_HEAD_FUSED (read once per process) select
+ *     kernel forms that are not the default for a shape; they exist for A/B measurements (tools/probes) and are covered by
+ *     tests/test_gpu_bf16.py.  Results are parity-tested in every form.
  */
 #ifndef ORN_H_
 #define ORN_H_
