@@ -670,6 +670,8 @@ __device__ __forceinline__ h16x8 tr_frag(const unsigned char *base0, const unsig
 
 // Both LDS images are filled by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction) into a 2-deep ring:
 // tile t+1 streams in while tile t feeds the matrix core; one barrier per tile; two work-groups per CU.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // the LDS-DMA asm names m0 as clobbered (nothing else in this function uses it)
 __device__ __forceinline__ void wgrad_body(const WgradBP &p, const int id)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -722,9 +724,14 @@ __device__ __forceinline__ void wgrad_body(const WgradBP &p, const int id)
         x_px[k] = L / 12;
         x_c[k] = L - x_px[k] * 12;
     }
+    // The LDS-DMA is issued through inline asm: behind the BUILTIN the compiler (which sees an LDS store it cannot tell apart
+    // from the buffer being read) puts `s_waitcnt vmcnt(0)` in front of the first fragment read of the CURRENT tile -- the wave
+    // then waits for the tile it has just requested before it starts the one it holds, and the 2-deep ring prefetches nothing.
+    // The one wait this ring needs is the explicit one at the top of the loop.
+    const unsigned wlds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
 #define WDMA16(gptr_, ldsoff_)                                                                                  \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr_),                   \
-                                     (__attribute__((address_space(3))) void *)(smem + (ldsoff_)), 16, 0, 0)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"   /* (one wait state between the M0 write and its use) */ \
+                 :: "s"(wlds0 + (unsigned)(ldsoff_)), "v"((const void *)(gptr_)) : "memory", "m0")
 #define WDMA_TILE(kt_, buf_)                                                                                    \
     {                                                                                                           \
         const int th_ = (kt_) / p.tiles_w, tw_ = (kt_) - th_ * p.tiles_w;                                       \
@@ -799,6 +806,7 @@ __device__ __forceinline__ void wgrad_body(const WgradBP &p, const int id)
             }
 }
 
+#pragma clang diagnostic pop
 __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16(WgradBP p) { wgrad_body(p, blockIdx.x); }
 
 // Several layers in one launch (problems in the order given, each on a multiple-of-8 block range so the XCD decode holds):
