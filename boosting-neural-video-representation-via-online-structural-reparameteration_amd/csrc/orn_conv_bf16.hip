@@ -732,10 +732,35 @@ __device__ __forceinline__ void wgrad_body(const WgradBP &p, const int id)
 #define WDMA16(gptr_, ldsoff_)                                                                                  \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"   /* (one wait state between the M0 write and its use) */ \
                  :: "s"(wlds0 + (unsigned)(ldsoff_)), "v"((const void *)(gptr_)) : "memory", "m0")
+    // same, source = wave-uniform base (SGPR pair) + per-lane 32-bit byte offset
+#define WDMA16S(sbase_, voff_, ldsoff_)                                                                         \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                               \
+                 :: "s"(wlds0 + (unsigned)(ldsoff_)), "v"(voff_), "s"((const void *)(sbase_)) : "memory", "m0")
+    // Interior tiles (every pixel of the tile inside the image: all but a ragged last column / row of tiles) take their
+    // addresses from per-lane offsets computed ONCE relative to the tile origin; the general form below redoes the index
+    // arithmetic and the bounds tests per piece -- ~25 vector instructions x 8 pieces per tile against 36 MFMAs.
+    unsigned dy_loff[DY_PW], x_loff[X_PW];
+#pragma unroll
+    for (int k = 0; k < DY_PW; ++k)
+        dy_loff[k] = (unsigned)(((dy_px[k] / WB_TW + 1) * (W + 2) + (dy_px[k] & (WB_TW - 1)) + 1) * O + o0 + dy_c[k] * 8) * 2u;
+#pragma unroll
+    for (int k = 0; k < X_PW; ++k) {
+        const int r = x_px[k] / WB_XW, c = x_px[k] - r * WB_XW;
+        x_loff[k] = x_px[k] < WB_TH * WB_XW ? (unsigned)(((r + ti) * (W + 2) + c) * 96 + x_c[k] * 8) * 2u : 0u;   // slots behind the patch: never read
+    }
 #define WDMA_TILE(kt_, buf_)                                                                                    \
     {                                                                                                           \
         const int th_ = (kt_) / p.tiles_w, tw_ = (kt_) - th_ * p.tiles_w;                                       \
         const int h0_ = th_ * WB_TH, w0_ = tw_ * WB_TW;                                                         \
+        if (h0_ + WB_TH <= H && w0_ + WB_TW <= W && !(PDBG(p) & 1)) {                                           \
+            const h16 *dyb_ = p.dypad + ((size_t)h0_ * (W + 2) + w0_) * O;                                      \
+            const h16 *xb_ = p.xpad + ((size_t)h0_ * (W + 2) + w0_) * 96;                                       \
+            _Pragma("unroll") for (int k = 0; k < DY_PW; ++k)                                                   \
+                WDMA16S(dyb_, dy_loff[k], (buf_) * WB_BUF_BYTES + (uwave + 4 * k) * 1024);                      \
+            _Pragma("unroll") for (int k = 0; k < X_PW; ++k)                                                    \
+                if (uwave + 4 * k < WB_X_INSTR)                                                                 \
+                    WDMA16S(xb_, x_loff[k], (buf_) * WB_BUF_BYTES + WB_DY_BYTES + (uwave + 4 * k) * 1024);      \
+        } else {                                                                                                \
         _Pragma("unroll") for (int k = 0; k < DY_PW; ++k) {                                                     \
             const int gh = h0_ + dy_px[k] / WB_TW, gw = w0_ + (dy_px[k] & (WB_TW - 1));                         \
             const bool ok = gh < H && gw < W && !(PDBG(p) & 1);                                                   \
@@ -751,6 +776,7 @@ __device__ __forceinline__ void wgrad_body(const WgradBP &p, const int id)
                 const h16 *src = ok ? p.xpad + ((size_t)gh * (W + 2) + gw) * 96 + x_c[k] * 8 : p.xpad + x_c[k] * 8; \
                 WDMA16(src, (buf_) * WB_BUF_BYTES + WB_DY_BYTES + (uwave + 4 * k) * 1024);                      \
             }                                                                                                   \
+        }                                                                                                       \
         }                                                                                                       \
     }
 
@@ -790,6 +816,7 @@ __device__ __forceinline__ void wgrad_body(const WgradBP &p, const int id)
         buf ^= 1;
     }
 #undef WDMA16
+#undef WDMA16S
 #undef WDMA_TILE
     bsum += __shfl_xor(bsum, 32);                             // the two K halves of the row
     if (o0 + wave * 32 >= O) return;                          // ragged last tile (O % 128 != 0): this wave's 32 channels do not exist
