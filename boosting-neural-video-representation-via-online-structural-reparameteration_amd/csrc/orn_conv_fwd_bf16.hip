@@ -555,7 +555,8 @@ int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p
     // and the SiLU in an epilogue that already spills), so blocks that write `apad` stay here unless ORN_FWD2_APAD is set.
     static const bool form1 = getenv("ORN_FWD_FORM1") != nullptr;         // tools/probes: A/B against this file's kernel
     static const bool form2_apad = getenv("ORN_FWD2_APAD") != nullptr;
-    if (!form1 && Cin == 96 && O % 96 == 0 && ptiles >= 128 && (!apad || form2_apad)) {
+    static const int min_tiles = getenv("ORN_FWD2_MINTILES") ? atoi(getenv("ORN_FWD2_MINTILES")) : 128;
+    if (!form1 && Cin == 96 && O % 96 == 0 && ptiles >= min_tiles && (!apad || form2_apad)) {
         const int rc = orn_launch_fwd2(xpad, wb, bias_p, H, W, O, s, z, apad, st, head);
         if (rc != -1) return rc;
     }
