@@ -297,7 +297,8 @@ def worker(args):
             step_us = dt / args.steps * 1e6
             out['roofline'] = {
                 'bound': 'mfma', 'achieved': dom['tflops'], 'peak': PEAK[args.precision], 'unit': 'TFLOP/s', 'frac': dom['frac'],
-                'traffic': traffic_for(dom['kernel']), 'kernel': dom['kernel'] + f" ({dom['launches_per_step']} launches/step; dominant by time)",
+                'traffic': traffic_for(dom['kernel']) if args.config == '720p' and args.precision == 'fp16' else None,   # the PMC file is the 720p fp16 step
+                'kernel': dom['kernel'] + f" ({dom['launches_per_step']} launches/step; dominant by time)",
                 'flops_per_launch': dom['gflop_per_step'] * 1e9 / dom['launches_per_step'],
                 'avg_launch_ms': dom['us_per_step'] / dom['launches_per_step'] / 1e3,
                 'kernels': kern,
