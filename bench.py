@@ -40,7 +40,7 @@ PEAK = {'fp32': 157.3, 'bf16': 2500.0, 'fp16': 2500.0}       # TFLOP/s: fp32 MFM
 SYM = {'fwd_last': 'k_conv_fwd_nhwc_bf16<4, 2, 2, 2, 3, 96, false>', 'fwd': 'k_conv_fwd_nhwc_bf16<4, 2, 2, 2, 0, 96, false>',
        'fwd_narrow': 'k_conv_fwd_nhwc_bf16<4, 2, 2, 2, 0, 32, true>',
        # >= 128 pixel tiles: the two-work-groups-per-CU family (orn_conv2_bf16.hip; template argument 0 dgrad, 2 forward of the last block)
-       'fwd_last_big': 'k_conv2_nhwc<2>', 'dgrad': 'k_conv2_nhwc<0>',
+       'fwd_last_big': 'k_conv2_nhwc<2>', 'fwd_big': 'k_conv2_nhwc<1>', 'dgrad': 'k_conv2_nhwc<0>',
        'dgrad_split': 'k_conv_nhwc_bf16<8, 1, 1, 3, 2, 96, false> + k_dgrad_finish',
        'dgrad_narrow': 'k_conv_nhwc_bf16<8, 1, 1, 1, 2, 96, true>', 'wgrad': 'k_wgrad_nhwc_bf16_all',
        'wgrad_reduce': 'k_wgrad_bf16_reduce_all'}
@@ -149,7 +149,8 @@ def conv_kernels(eng, precision, cfg, iters=20):
             narrow = L['C'] <= 32
             tiles = ((L['W'] + 31) // 32) * ((L['H'] + 7) // 8)
             big_last = i == nl - 1 and tiles >= 128 and L['O'] % 96 == 0                       # orn_launch_conv_bf16_fwd
-            add(ns + (SYM['fwd_last_big'] if big_last else SYM['fwd_last'] if i == nl - 1 else (SYM['fwd_narrow'] if narrow else SYM['fwd'])),
+            big_mid = i < nl - 1 and tiles >= 400 and L['O'] % 96 == 0 and not narrow          # (blocks that write the activation copy)
+            add(ns + (SYM['fwd_last_big'] if big_last else SYM['fwd_last'] if i == nl - 1 else SYM['fwd_big'] if big_mid else (SYM['fwd_narrow'] if narrow else SYM['fwd'])),
                 fwd[i], L['flops'])
             small = tiles < 128 and L['O'] // 96 > 1                                            # orn_launch_conv_bf16_dgrad
             if i == ff:

@@ -550,13 +550,14 @@ int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p
     const float cost_split = (float)orn_cdiv(ptiles * nt_total, 256) * 1.3f;
     p.n_tiles_per_wg = (ptiles >= 512 || cost_whole <= cost_split) ? nt_total : 1;
     if (apad && c_real > 0 && c_real <= 32) return launch_convf_cfg<4, 2, 2, 2, EPI_B_FWD, 32>(p, nt_total, st);
-    // large images with whole 96-channel N tiles: the two-work-groups-per-CU form (orn_conv2_bf16.hip).  Measured in the 720p
-    // step: last block (z only) 150 -> 140 us, but the 180 x 320 block WITH the activation copy 41 -> 54 us (twice the stores
-    // and the SiLU in an epilogue that already spills), so blocks that write `apad` stay here unless ORN_FWD2_APAD is set.
+    // large images with whole 96-channel N tiles: the two-work-groups-per-CU form (orn_conv2_bf16.hip).  Measured in the step:
+    // the last block (z only) 150 -> 140 us at 720p; blocks that also write the activation copy are neutral at 230 pixel tiles
+    // (720p, 180 x 320: 74.2 vs 73.9 us for the two such launches) and gain from ~500 tiles on (1080p: 181 -> 168 us for its
+    // three), so those take it from 400 tiles (ORN_FWD2_APAD: always).
     static const bool form1 = getenv("ORN_FWD_FORM1") != nullptr;         // tools/probes: A/B against this file's kernel
     static const bool form2_apad = getenv("ORN_FWD2_APAD") != nullptr;
     static const int min_tiles = getenv("ORN_FWD2_MINTILES") ? atoi(getenv("ORN_FWD2_MINTILES")) : 128;
-    if (!form1 && Cin == 96 && O % 96 == 0 && ptiles >= min_tiles && (!apad || form2_apad)) {
+    if (!form1 && Cin == 96 && O % 96 == 0 && ptiles >= min_tiles && (!apad || ptiles >= 400 || form2_apad)) {
         const int rc = orn_launch_fwd2(xpad, wb, bias_p, H, W, O, s, z, apad, st, head);
         if (rc != -1) return rc;
     }
