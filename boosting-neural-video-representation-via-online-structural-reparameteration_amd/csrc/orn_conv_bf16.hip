@@ -950,9 +950,10 @@ int orn_wgrad_bf16_split(int H, int W, int O)
     int S = (512 / per) / 8 * 8;
     static const int s_env = getenv("ORN_WGRAD_SMAX") ? atoi(getenv("ORN_WGRAD_SMAX")) : 0;      // tools/probes: split-K sweep
     if (s_env > 0 && S > s_env) S = s_env;
-    // measured at the 720p shapes: below ~2000 K tiles a full wave of work-groups makes the slab write + re-read cost
-    // more than the idle CUs do (L3, 900 tiles: 40 slabs beat 56 by 17 us per step)
-    if (n_ktiles < 2000 && S > 40) S = 40;
+    // measured in the 720p step: a full wave of work-groups (56 slabs) makes the slab write + re-read cost more than the idle
+    // slots do -- L3 (900 K tiles): 40 slabs beat 56 by 17 us; L4 (3600 K tiles), since the DMA prefetch of the K loop works:
+    // 32 / 40 / 48 / 56 slabs = 1.148 / 1.128 / 1.133 / 1.143 ms per step (reduction 30 / 35 / 38 / 45 us, wgrad 224 / 199 / 199 / 201)
+    if (S > 40) S = 40;
     const int by_work = (n_ktiles / 8) / 8 * 8;
     if (S > by_work) S = by_work;
     if (S < 8) S = 8;
