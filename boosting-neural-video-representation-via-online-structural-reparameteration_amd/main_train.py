@@ -131,6 +131,20 @@ def save_checkpoint(args, model, eng, epoch, best_psnr, name='model_latest.pth')
                         deploy=True)
 
 
+def skipped_steps_warning(skipped_before: int, skipped_now: int, steps: int, precision: str, scale: float):
+    """The non-finite guard leaves parameters and Adam state untouched by a step whose loss or gradients are not finite and
+    backs the loss scale off; a few such steps are its normal work.  An epoch in which MOST steps were skipped means the fit
+    itself has left the number range (on some content the reference recipe blows up while its LR is still ramping --
+    DESIGN.md section 5 -- and fp16 activations then overflow in the forward, where no scale can help): say so instead of
+    training on in silence.  Returns the warning line or None."""
+    d = skipped_now - skipped_before
+    if steps <= 0 or 2 * d <= steps:
+        return None
+    return (f'WARNING: {d} of {steps} steps of this epoch were skipped (non-finite loss or gradients; loss scale now {scale:g}). '
+            f'The fit has left the range of --precision {precision}; skipped steps change nothing, so it will not recover by itself. '
+            f'Re-run with --precision fp32' + (' or bf16' if precision == 'fp16' else '') + ' or a lower --lr.')
+
+
 def adam_state_dict(model, eng, args):
     """The optimizer entry of a checkpoint in torch.optim.Adam's own state_dict layout (per-parameter 'step' / 'exp_avg' /
     'exp_avg_sq' in model.parameters() order + one param group), so the reference's
@@ -234,6 +248,7 @@ def fit_video(args, name, vid_index, rank):
     best = torch.tensor(0.0)
     start = time.time()
     steps_per_epoch = min(n, 11) if args.debug else n
+    skipped_before = 0
     for epoch in range(args.epochs):
         g.manual_seed(args.manualSeed + epoch)
         order = torch.randperm(n, generator=g).tolist()[:steps_per_epoch]
@@ -256,6 +271,12 @@ def fit_video(args, name, vid_index, rank):
             print(msg, file=log, flush=True)
         if (args.ckpt_freq and (epoch + 1) % args.ckpt_freq == 0) or (not args.ckpt_freq and is_eval) or epoch == args.epochs - 1:
             save_checkpoint(args, model, eng, epoch, best)
+        sc = eng.scale_state()                                       # (the stats read above has already synchronised)
+        warn = skipped_steps_warning(skipped_before, sc['skipped'], len(entries), args.precision, sc['scale'])
+        skipped_before = sc['skipped']
+        if warn:
+            print(warn, flush=True)
+            print(warn, file=log, flush=True)
     torch.cuda.synchronize()
     sc = eng.scale_state()
     if sc['skipped']:

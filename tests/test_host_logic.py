@@ -327,3 +327,15 @@ def test_per_rank_outputs_do_not_collide(orn):
     assert sv == ['synthetic0', 'synthetic1'] and main_train.video_outf('o', sv, 1) == 'o/synthetic1'
     A.synthetic, A.dataset = 0, 'bunny'
     assert main_train.video_outf('result/b', main_train.video_list(A, 1), 0) == 'result/b'       # single video: reference layout
+
+
+def test_skipped_steps_warning():
+    """main_train's dead-fit detector: silent while the guard does its normal work, loud when most of an epoch was skipped."""
+    from orn_amd import main_train as mt
+    assert mt.skipped_steps_warning(0, 0, 132, 'fp16', 2.0 ** 20) is None
+    assert mt.skipped_steps_warning(10, 14, 132, 'fp16', 2.0 ** 19) is None             # a handful of back-offs
+    assert mt.skipped_steps_warning(10, 76, 132, 'fp16', 2.0 ** 19) is None             # exactly half: still quiet
+    w = mt.skipped_steps_warning(10, 142, 132, 'fp16', 1.0)
+    assert w and '132 of 132' in w and 'fp32' in w and 'bf16' in w
+    w = mt.skipped_steps_warning(0, 100, 132, 'fp32', 1.0)
+    assert w and 'bf16' not in w
