@@ -19,8 +19,9 @@
 //   | 24 MFMAs | DMA of weight tile u+4 into the slot of tile u | (taps 0..5) one DMA piece of the NEXT chunk's patch.
 //   What is known to have landed after rendezvous v: weight tiles <= v+2 and the patch pieces issued up to step v-2, because the
 //   wait before rendezvous v leaves exactly the operations issued after rendezvous v-1 in flight (vmcnt counts in issue order).
-//   Every wave issues the same operations at every step, so those waits are compile-time constants and a tap is one basic block
-//   (a runtime branch inside it cost 50 us per launch: the scheduler no longer interleaves the next reads with the MFMAs).
+//   The body is compiled once per wave (its DMA role: which pieces of a step it issues), so those waits are compile-time
+//   constants and a tap is one basic block (a runtime branch inside it cost 50 us per launch: the scheduler no longer
+//   interleaves the next reads with the MFMAs).
 // Compiled twice like its siblings: as is (bf16, namespace orn_bf16) and with -DORN_FP16 (IEEE half, namespace orn_f16).
 #include "orn_internal.h"
 #include <type_traits>
@@ -167,21 +168,26 @@ __device__ __forceinline__ void c2_mfma_step(h16x8 (&fa)[2][4], h16x8 (&fb)[2][6
 #pragma unroll
         for (int j = 0; j < 6; ++j) acc[i][j] = MFMA16_H16(fb[SET][j], fa[SET][i], acc[i][j]);
 }
-// patch pieces (of the next chunk) a wave issues at tap t: all six within the first 7 - LAG taps, so that they are known to have
-// landed at the rendezvous of tap 7, in front of which tap 8 prefetches the next chunk's first fragments
-#define C2_LAG (C2_NSLOT - 3)
-constexpr int c2_npp(int t) { constexpr int n = 7 - C2_LAG; return t >= n ? 0 : (6 / n + (t < 6 % n ? 1 : 0)); }
-constexpr int c2_ppbase(int t) { int b = 0; for (int i = 0; i < t; ++i) b += c2_npp(i); return b; }
-constexpr int c2_inflight(int t) { int n = 0; for (int i = 1; i <= C2_LAG; ++i) n += 2 + c2_npp((t - i + 9) % 9); return n; }
-static_assert(c2_ppbase(9) == 6 && C2_LAG >= 1 && C2_LAG <= 4, "conv2: patch piece schedule");
 template <int N> __device__ __forceinline__ void c2_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-template <int EPI>
-__global__ void __launch_bounds__(256, 2) k_conv2_nhwc(Conv2P p)
+// DMA roles.  A step's pieces -- the 6 of weight tile u+4, then (taps 0..5) 4, 4, 4, 4, 3, 3 of the next patch's 22 -- are dealt
+// round-robin to the four waves: wave R issues the pieces at list positions R, R+4, R+8.  The per-wave count of a step differs
+// between waves, and the counted waits need it as an immediate, so the whole body is compiled once per wave (template
+// argument ROLE, selected once at the top of the kernel: no branch inside the loop): 76 DMA instructions per chunk and
+// work-group instead of the 108 of a role-free stream that pads every wave to the same count with pieces loaded twice.
+constexpr int c2_wcnt(int role) { return role < 2 ? 2 : 1; }                              // weight pieces j = role, role + 4 (< 6)
+constexpr int c2_pn(int t) { return t < 4 ? 4 : (t < 6 ? 3 : 0); }                        // patch pieces dealt at tap t
+constexpr int c2_pbase(int t) { int b = 0; for (int i = 0; i < t; ++i) b += c2_pn(i); return b; }
+constexpr int c2_pidx(int role, int t) { const int n = (role + 2) & 3; return n < c2_pn(t) ? c2_pbase(t) + n : -1; }   // list position 6 + n has (6 + n) % 4 == role
+constexpr int c2_cnt(int role, int t) { return c2_wcnt(role) + (c2_pidx(role, t) >= 0 ? 1 : 0); }
+static_assert(c2_pbase(6) == C2_PATCH_INSTR && C2_NSLOT == 4, "conv2: the piece deal assumes 22 patch pieces and the 4-deep ring (LAG 1)");
+
+template <int EPI, int ROLE>
+__device__ __forceinline__ void c2_body(const Conv2P &p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63;
-    const int uwave = __builtin_amdgcn_readfirstlane(t >> 6);
+    constexpr int uwave = ROLE;
     const int l15 = lane & 15, g4 = lane >> 4;
     // forward: the `nsplit` work-groups of a pixel tile follow each other on one XCD (work-groups go round the 8 XCDs), so the
     // patch the first of them pulls from HBM is an L2 hit for the others
@@ -198,13 +204,11 @@ __global__ void __launch_bounds__(256, 2) k_conv2_nhwc(Conv2P p)
     const int H = p.H, W = p.W, Cx = p.Cx;
     const int QS = p.qseg;
 
-    // DMA plans: per-lane SOURCE byte offsets; destination = lane-linear 1 KiB per instruction.  Every wave issues the same
-    // operations at every step (patch: 24 issue slots for 22 instructions, weight tile: 8 for 6 -- the surplus ones load a piece
-    // twice; past the end of the stream the loads wrap around into buffers nobody reads any more).
-    unsigned p_goff[6], b_goff[2];
+    // DMA plans: per-lane SOURCE byte offsets of this wave's pieces; destination = lane-linear 1 KiB per instruction.
+    unsigned p_goff[6], b_goff[2];                       // patch piece of tap k (0..5, if this role has one); weight pieces j = ROLE, ROLE + 4
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        const int m = (uwave + 4 * k) % C2_PATCH_INSTR;
+        const int m = c2_pidx(ROLE, k) >= 0 ? c2_pidx(ROLE, k) : 0;
         const int L = m * 64 + lane, pix = L >> 2, pos = L & 3;
         const int c = pos ^ ((pix >> 1) & 3);
         const int pr = pix / C2_PW, pc = pix - pr * C2_PW;
@@ -214,23 +218,23 @@ __global__ void __launch_bounds__(256, 2) k_conv2_nhwc(Conv2P p)
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const int m = (uwave * 2 + k) % 6;
+        const int m = ROLE + 4 * k;                      // (k = 1 only exists for roles 0 and 1)
         const int L = m * 64 + lane, R = L >> 2, pos = L & 3;
         b_goff[k] = (unsigned)(R * p.wrow + (pos ^ ((R >> 1) & 3)) * 8) * 2u;
     }
 #define C2_DMA16(gptr_, ldsoff_)                                                                                \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr_),                   \
                                      (__attribute__((address_space(3))) void *)(smem + (ldsoff_)), 16, 0, 0)
-    // piece k_ of the patch of source chunk qsrc_ into patch buffer buf_
+    // this wave's patch piece of tap k_ (if it has one) of source chunk qsrc_ into patch buffer buf_
 #define C2_DMA_PATCH_PIECE(qsrc_, buf_, k_)                                                                     \
-    C2_DMA16((const char *)p.xpad + (size_t)(qsrc_) * (C2_CK * 2) + p_goff[k_],                                 \
-             (buf_) * C2_PATCH_LDS + ((uwave + 4 * (k_)) % C2_PATCH_INSTR) * 1024);
-    // weight tile (rows and chunk of wq_, tap tap_) into ring slot slot_
+    if constexpr (c2_pidx(ROLE, (k_)) >= 0)                                                                     \
+        C2_DMA16((const char *)p.xpad + (size_t)(qsrc_) * (C2_CK * 2) + p_goff[k_], (buf_) * C2_PATCH_LDS + c2_pidx(ROLE, (k_)) * 1024);
+    // this wave's pieces of the weight tile (rows and chunk of wq_, tap tap_) into ring slot slot_
 #define C2_DMA_TILE_AT(wq_, tap_, slot_)                                                                        \
     {                                                                                                           \
         const char *wb__ = (const char *)(wq_) + (size_t)(tap_) * p.wtap;                                       \
-        _Pragma("unroll") for (int k = 0; k < 2; ++k)                                                           \
-            C2_DMA16(wb__ + b_goff[k], 2 * C2_PATCH_LDS + (slot_) * C2_TILE_BYTES + ((uwave * 2 + k) % 6) * 1024); \
+        _Pragma("unroll") for (int k = 0; k < c2_wcnt(ROLE); ++k)                                               \
+            C2_DMA16(wb__ + b_goff[k], 2 * C2_PATCH_LDS + (slot_) * C2_TILE_BYTES + (ROLE + 4 * k) * 1024);     \
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
     const unsigned pix_lane = (2 * uwave) * C2_PW + l15;                                  // patch pixel of (row 2w, column l15)
@@ -267,8 +271,7 @@ __global__ void __launch_bounds__(256, 2) k_conv2_nhwc(Conv2P p)
 
     // prologue: patch of chunk 0, weight tiles 0..R-2, rendezvous; tile R-1 stays in flight behind it
     const h16 *w_cur = p.w + (size_t)seg0 * 96 * p.wrow;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) C2_DMA_PATCH_PIECE(0, 0, k)
+    c2_sfor<0, 6>([&](auto k_c) __attribute__((always_inline)) { C2_DMA_PATCH_PIECE(0, 0, decltype(k_c)::value) });
 #pragma unroll
     for (int u0 = 0; u0 < C2_NSLOT - 1; ++u0) C2_DMA_TILE_AT(w_cur, u0, u0)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -304,16 +307,14 @@ __global__ void __launch_bounds__(256, 2) k_conv2_nhwc(Conv2P p)
             // u + 2 - R) and, at tap 7, the next chunk's patch: everything issued up to step u - (R - 2).  So the operations of
             // the LAG = R - 3 steps before this one stay in flight: per step two weight pieces + that step's patch pieces.
             // (A forward epilogue's stores are older than all of these: the first rendezvous after it waits for them.)
-            c2_wait_vm<c2_inflight(tap)>();
+            c2_wait_vm<c2_cnt(ROLE, (tap + 8) % 9)>();
             __builtin_amdgcn_s_barrier();
             c2_mfma_step<cur>(fa, fb, acc);
 #ifndef C2_ABL_NO_WDMA            // compile-time timing ablations (tools/probes/abl_conv2.sh)
             C2_DMA_TILE_AT((tap + C2_NSLOT < 9) ? w_cur : w_nxt, (tap + C2_NSLOT) % 9, (slot_c + tap) % C2_NSLOT)   // into the slot of tile u: everyone is past its reads
 #endif
 #ifndef C2_ABL_NO_PDMA
-            c2_sfor<0, c2_npp(tap)>([&](auto k_c) __attribute__((always_inline)) {           // next chunk's patch
-                C2_DMA_PATCH_PIECE(qn, (c + 1) & 1, c2_ppbase(tap) + decltype(k_c)::value)
-            });
+            C2_DMA_PATCH_PIECE(qn, (c + 1) & 1, tap)                                       // next chunk's patch
 #endif
         });
         slot_c = (slot_c + 9) % C2_NSLOT;
@@ -438,6 +439,17 @@ __global__ void __launch_bounds__(256, 2) k_conv2_nhwc(Conv2P p)
                 }
             }
         }
+    }
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(256, 2) k_conv2_nhwc(Conv2P p)
+{
+    switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {       // one copy of the body per DMA role (wave-uniform)
+    case 0: c2_body<EPI, 0>(p); break;
+    case 1: c2_body<EPI, 1>(p); break;
+    case 2: c2_body<EPI, 2>(p); break;
+    default: c2_body<EPI, 3>(p); break;
     }
 }
 
