@@ -28,7 +28,9 @@ def _half_round(t, half):
 @pytest.mark.parametrize('C,O,H,W,s', [(96, 384, 8, 32, 2), (96, 384, 36, 64, 2), (96, 384, 45, 80, 2), (96, 384, 13, 37, 2),
                                        (96, 1152, 9, 33, 3), (96, 864, 10, 33, 3),
                                        # >= 128 pixel tiles: the forward takes the two-work-groups-per-CU form (whole and ragged tiles, s = 2 / 3)
-                                       (96, 384, 64, 512, 2), (96, 384, 67, 500, 2), (96, 864, 66, 480, 3)])
+                                       (96, 384, 64, 512, 2), (96, 384, 67, 500, 2), (96, 864, 66, 480, 3),
+                                       # >= 400 tiles, ragged in both directions: the same kernel for blocks that also write the activation copy
+                                       (96, 384, 100, 1030, 2)])
 def test_bf16_block_fwd_bwd(orn, C, O, H, W, s, half):
     """conv3x3+PixelShuffle+SiLU fwd, and dbias / wgrad / dgrad, on 16-bit MFMA -- the bf16 build AND the IEEE-half build
     the engine's fp16 mode (bench.py's headline) launches -- vs the CPU oracle run on the SAME 16-bit-rounded inputs
