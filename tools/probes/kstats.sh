@@ -27,3 +27,4 @@ for per, c, k in sorted(out, reverse=True):
 print(f'{tot:8.1f} us/step total ({steps} steps incl. profile/eager steps)')
 PY
 tail -2 /tmp/ks_$tag.log | cut -c1-300 >> $GRAFT_REPO_ROOT/gpurun_out/kstats_$tag.txt
+cp $(find /tmp/ks_$tag -name "*kernel_stats.csv" | head -1) $GRAFT_REPO_ROOT/gpurun_out/kstats_${tag}_rocprof_stats.csv 2>/dev/null
