@@ -954,6 +954,10 @@ int orn_wgrad_bf16_split(int H, int W, int O)
     // slots do -- L3 (900 K tiles): 40 slabs beat 56 by 17 us; L4 (3600 K tiles), since the DMA prefetch of the K loop works:
     // 32 / 40 / 48 / 56 slabs = 1.148 / 1.128 / 1.133 / 1.143 ms per step (reduction 30 / 35 / 38 / 45 us, wgrad 224 / 199 / 199 / 201)
     if (S > 40) S = 40;
+    // layers under 2000 K tiles (720p L3: 900): 24 slabs -- the wgrad launch does not notice (all layers share it), the reduction
+    // reads less: 40 / 32 / 24 = 35 / 32 / 30 us
+    static const int s_small = getenv("ORN_WGRAD_SMAX_SMALL") ? atoi(getenv("ORN_WGRAD_SMAX_SMALL")) : 24;   // tools/probes override
+    if (n_ktiles < 2000 && S > s_small) S = s_small;
     const int by_work = (n_ktiles / 8) / 8 * 8;
     if (S > by_work) S = by_work;
     if (S < 8) S = 8;
