@@ -56,12 +56,23 @@ def deploy_state_dict(model) -> Dict[str, torch.Tensor]:
     return out
 
 
-def save(path: str, model, epoch: int, optimizer_state=None, train_best_psnr=None, val_best_psnr=None, deploy: bool = False):
+def deploy_param_count(model) -> int:
+    """Parameters of the deploy-state model (main_train.py:362-364, "Deploy Rep-Model Params")."""
+    return sum(v.numel() for v in deploy_state_dict(model).values())
+
+
+def save(path: str, model, epoch: int, optimizer_state=None, train_best_psnr=None, val_best_psnr=None, deploy: bool = False,
+         train_best_msssim=None, val_best_msssim=None):
+    """One checkpoint file in the reference's layout (main_train.py:293-301); the four best-so-far entries are 0-d tensors
+    as the reference leaves them."""
     sd = deploy_state_dict(model) if deploy else {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     zero = torch.tensor(0)
+
+    def t(x):
+        return zero if x is None else torch.as_tensor(x).detach().cpu().reshape(())
     ck = {'epoch': epoch, 'state_dict': sd,
-          'train_best_psnr': train_best_psnr if train_best_psnr is not None else zero, 'train_best_msssim': zero,
-          'val_best_psnr': val_best_psnr if val_best_psnr is not None else zero, 'val_best_msssim': zero,
+          'train_best_psnr': t(train_best_psnr), 'train_best_msssim': t(train_best_msssim),
+          'val_best_psnr': t(val_best_psnr), 'val_best_msssim': t(val_best_msssim),
           'optimizer': optimizer_state if optimizer_state is not None else {}}
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     torch.save(ck, path)

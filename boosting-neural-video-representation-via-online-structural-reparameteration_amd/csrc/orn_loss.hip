@@ -21,56 +21,97 @@ struct LossP {
     const int *frame_idx;      // optional device index selecting the target frame
     size_t frame_stride;
     int planes, H, W, Hv, Wv;  // planes = B*Ch
-    float *dm, *dq, *dr;       // [planes][Hv][Wv]
-    float *part_ssim;          // [n_blocks_ssim]
-    float *part_l1;            // [n_blocks_grad][2]
+    float *part_ssim;          // [n_blocks]
+    float *part_l1;            // [n_blocks][2]
     float *dpred;              // may be null
     int loss_type;
+    int vec4;                  // W % 4 == 0 and 16-byte aligned planes: the fused Fusion6 kernel loads float4
     float g_l1, g_l2, g_ssim;  // gradient scales (already include loss_scale and 1/n)
-    int tiles_w_v, tiles_h_v, tiles_w, tiles_h;
+    int tiles_w, tiles_h;
 };
 
-// Register-blocked separable filtering: every thread produces 4 adjacent outputs from a 14-wide window
-// (3x fewer LDS reads than one output per thread).
-__global__ void __launch_bounds__(256) k_ssim_stats(LossP q)
+// Fusion6 in ONE pass per image tile (round 3; rounds 1-2 ran k_ssim_stats + k_loss_grad with the three dS maps making a
+// round trip through HBM).  A work-group owns a 16x64 tile of dL/dpred.  It needs the dS maps on the tile + a 10-pixel apron
+// (adjoint of the valid 11x11 filter), hence p and t on the tile + a 20-pixel apron: the five filtered maps and the three dS
+// maps are RECOMPUTED on the apron (2.9x / 1.9x the arithmetic of the tile alone: the separable filters are cheap VALU work)
+// and never leave LDS.  HBM traffic: p, t read (aprons from L2), dL/dpred written.  Register-blocked separable filtering:
+// every thread produces 4 adjacent outputs from a 14-wide window (3x fewer LDS reads than one output per thread).
+//   LDS (80 KB, two work-groups per CU):  X [2][36][88] p, t patch | Hm [5][36][76] row-filtered p, t, p^2, t^2, pt
+//                                         D [3][26][76] dS/dm, dS/dq, dS/dr (over X) | Hh [3][26][64] row-adjoint of D (over Hm)
+#define F6_TH 16
+#define F6_TW 64
+#define F6_PH (F6_TH + 20)
+#define F6_PWP 88            // 84 columns used
+#define F6_DH (F6_TH + 10)
+#define F6_DWP 76            // 74 columns used
+#define F6_LDS_FLOATS (2 * F6_PH * F6_PWP + 5 * F6_PH * F6_DWP + 16)
+
+template <bool GRAD>
+__global__ void __launch_bounds__(256) k_fusion6(LossP q)
 {
-    __shared__ __attribute__((aligned(16))) float Ps[SS_PH][SS_PWP];
-    __shared__ __attribute__((aligned(16))) float Ts[SS_PH][SS_PWP];
-    __shared__ __attribute__((aligned(16))) float Hs[5][SS_PH][SS_TW];
-    __shared__ float sred[16];
+    extern __shared__ __attribute__((aligned(16))) float f6s[];
+    float *Xp = f6s, *Xt = f6s + F6_PH * F6_PWP;
+    float *Hm = f6s + 2 * F6_PH * F6_PWP;
+    float *Dm = f6s;                       // written after the last read of Xp / Xt
+    float *Hh = Hm;                        // written after the last read of Hm
+    float *sred = f6s + 2 * F6_PH * F6_PWP + 5 * F6_PH * F6_DWP;
     const int t = threadIdx.x;
     const int plane = blockIdx.y;
-    const int tw = blockIdx.x % q.tiles_w_v, th = blockIdx.x / q.tiles_w_v;
-    const int y0 = th * SS_TH, x0 = tw * SS_TW;         // valid-map coords == image coords of the window origin
+    const int tw = blockIdx.x % q.tiles_w, th = blockIdx.x / q.tiles_w;
+    const int y0 = th * F6_TH, x0 = tw * F6_TW;
     const size_t HW = (size_t)q.H * q.W;
     const float *pp = q.pred + (size_t)plane * HW;
     const float *tp = q.target + (q.frame_idx ? (size_t)(*q.frame_idx) * q.frame_stride : 0) + (size_t)plane * HW;
-    {   // all global loads in flight before the first LDS write
-        constexpr int NL = (SS_PH * SS_PWP + 255) / 256;
-        float ra[NL], rb[NL];
+    // ---- patch rows y0-10 .. y0+25, columns x0-10 .. x0+73 (LDS column c <-> image column x0 - 10 + c); zero outside the image
+    if (q.vec4) {           // rows are 16-byte aligned: float4 units from image column x0 - 12
+        constexpr int NU = 22, NIT = (F6_PH * NU + 255) / 256;
+        float4 ra[NIT], rb[NIT];
 #pragma unroll
-        for (int it = 0; it < NL; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             const int idx = t + it * 256;
-            const int r = idx / SS_PWP, c = idx - r * SS_PWP;
-            const int gy = y0 + r, gx = x0 + c;
-            ra[it] = 0.f; rb[it] = 0.f;
-            if (idx < SS_PH * SS_PWP && c < SS_PW && gy < q.H && gx < q.W) { ra[it] = pp[(size_t)gy * q.W + gx]; rb[it] = tp[(size_t)gy * q.W + gx]; }
+            const int r = idx / NU, u = idx - r * NU;
+            const int gy = y0 - 10 + r, gx = x0 - 12 + 4 * u;
+            ra[it] = make_float4(0.f, 0.f, 0.f, 0.f); rb[it] = ra[it];
+            if (idx < F6_PH * NU && gy >= 0 && gy < q.H && gx >= 0 && gx < q.W) {
+                ra[it] = *reinterpret_cast<const float4 *>(pp + (size_t)gy * q.W + gx);
+                rb[it] = *reinterpret_cast<const float4 *>(tp + (size_t)gy * q.W + gx);
+            }
         }
 #pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = t + it * 256;
+            const int r = idx / NU, u = idx - r * NU;
+            if (idx < F6_PH * NU) {
+                const int c = 4 * u - 2;
+                if (u > 0) {
+                    *reinterpret_cast<float2 *>(Xp + r * F6_PWP + c) = make_float2(ra[it].x, ra[it].y);
+                    *reinterpret_cast<float2 *>(Xt + r * F6_PWP + c) = make_float2(rb[it].x, rb[it].y);
+                }
+                *reinterpret_cast<float2 *>(Xp + r * F6_PWP + c + 2) = make_float2(ra[it].z, ra[it].w);
+                *reinterpret_cast<float2 *>(Xt + r * F6_PWP + c + 2) = make_float2(rb[it].z, rb[it].w);
+            }
+        }
+    } else {
+        constexpr int NL = (F6_PH * F6_PWP + 255) / 256;
+#pragma unroll 1
         for (int it = 0; it < NL; ++it) {
             const int idx = t + it * 256;
-            if (idx < SS_PH * SS_PWP) { (&Ps[0][0])[idx] = ra[it]; (&Ts[0][0])[idx] = rb[it]; }
+            const int r = idx / F6_PWP, c = idx - r * F6_PWP;
+            const int gy = y0 - 10 + r, gx = x0 - 10 + c;
+            float a = 0.f, b = 0.f;
+            if (idx < F6_PH * F6_PWP && gy >= 0 && gy < q.H && gx >= 0 && gx < q.W) { a = pp[(size_t)gy * q.W + gx]; b = tp[(size_t)gy * q.W + gx]; }
+            if (idx < F6_PH * F6_PWP) { Xp[idx] = a; Xt[idx] = b; }
         }
     }
     __syncthreads();
-    // horizontal pass: item = (row r, 4 columns c4..c4+3)
-    for (int idx = t; idx < SS_PH * (SS_TW / 4); idx += 256) {
-        const int r = idx / (SS_TW / 4), c4 = (idx - r * (SS_TW / 4)) * 4;
+    // ---- row filter: Hm[m][r][j] = sum_k g[k] X[r][j + k], j < 76 (74 used); item = (row r, 4 columns)
+    for (int idx = t; idx < F6_PH * (F6_DWP / 4); idx += 256) {
+        const int r = idx / (F6_DWP / 4), c4 = (idx - r * (F6_DWP / 4)) * 4;
         float a[16], b[16];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float4 va = *reinterpret_cast<const float4 *>(&Ps[r][c4 + 4 * k]);
-            const float4 vb = *reinterpret_cast<const float4 *>(&Ts[r][c4 + 4 * k]);
+            const float4 va = *reinterpret_cast<const float4 *>(Xp + r * F6_PWP + c4 + 4 * k);
+            const float4 vb = *reinterpret_cast<const float4 *>(Xt + r * F6_PWP + c4 + 4 * k);
             a[4 * k] = va.x; a[4 * k + 1] = va.y; a[4 * k + 2] = va.z; a[4 * k + 3] = va.w;
             b[4 * k] = vb.x; b[4 * k + 1] = vb.y; b[4 * k + 2] = vb.z; b[4 * k + 3] = vb.w;
         }
@@ -91,25 +132,28 @@ __global__ void __launch_bounds__(256) k_ssim_stats(LossP q)
                 }
             }
         }
-        // 16-byte stores: scalar ones put the 4 rows of a wave on the same 16 banks (4-way conflicts)
-        *reinterpret_cast<float4 *>(&Hs[0][r][c4]) = make_float4(sp[0], sp[1], sp[2], sp[3]);
-        *reinterpret_cast<float4 *>(&Hs[1][r][c4]) = make_float4(st[0], st[1], st[2], st[3]);
-        *reinterpret_cast<float4 *>(&Hs[2][r][c4]) = make_float4(spp[0], spp[1], spp[2], spp[3]);
-        *reinterpret_cast<float4 *>(&Hs[3][r][c4]) = make_float4(stt[0], stt[1], stt[2], stt[3]);
-        *reinterpret_cast<float4 *>(&Hs[4][r][c4]) = make_float4(spt[0], spt[1], spt[2], spt[3]);
+        float *h = Hm + r * F6_DWP + c4;
+        *reinterpret_cast<float4 *>(h) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+        *reinterpret_cast<float4 *>(h + F6_PH * F6_DWP) = make_float4(st[0], st[1], st[2], st[3]);
+        *reinterpret_cast<float4 *>(h + 2 * F6_PH * F6_DWP) = make_float4(spp[0], spp[1], spp[2], spp[3]);
+        *reinterpret_cast<float4 *>(h + 3 * F6_PH * F6_DWP) = make_float4(stt[0], stt[1], stt[2], stt[3]);
+        *reinterpret_cast<float4 *>(h + 4 * F6_PH * F6_DWP) = make_float4(spt[0], spt[1], spt[2], spt[3]);
     }
     __syncthreads();
+    // ---- column filter + SSIM map + dS maps on valid-map rows y0-10+i (i < 26), columns x0-10+j (j < 74).
+    // item = (column j, 9 rows); the third row group restarts at row 17 (rows 17..25: row 17 is computed twice, same value)
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     float ssum = 0.f;
-    {   // vertical pass: item = (column c, RPT rows r4..r4+RPT-1); 256 items = one per thread
-        constexpr int RPT = SS_TH * SS_TW / 256;
-        const int c = t & (SS_TW - 1), r4 = (t / SS_TW) * RPT;
+    if (t < 3 * F6_DWP) {
+        constexpr int RPT = 9;
+        const int rg = t / F6_DWP, j = t - rg * F6_DWP;
+        const int r4 = rg == 2 ? 17 : rg * RPT;
         float v[5][RPT];
 #pragma unroll
         for (int m = 0; m < 5; ++m) {
             float col[RPT + 10];
 #pragma unroll
-            for (int k = 0; k < RPT + 10; ++k) col[k] = Hs[m][r4 + k][c];
+            for (int k = 0; k < RPT + 10; ++k) col[k] = Hm[(m * F6_PH + r4 + k) * F6_DWP + j];
 #pragma unroll
             for (int o = 0; o < RPT; ++o) {
                 float acc = 0.f;
@@ -120,73 +164,38 @@ __global__ void __launch_bounds__(256) k_ssim_stats(LossP q)
         }
 #pragma unroll
         for (int o = 0; o < RPT; ++o) {
-            const int gy = y0 + r4 + o, gx = x0 + c;
-            if (gy >= q.Hv || gx >= q.Wv) continue;
-            const float m = v[0][o], mu = v[1][o], qq = v[2][o], tt = v[3][o], rr = v[4][o];
-            const float sp = qq - m * m, st = tt - mu * mu, spt = rr - m * mu;
-            const float A1 = 2.f * m * mu + C1, A2 = 2.f * spt + C2;
-            const float B1 = m * m + mu * mu + C1, B2 = sp + st + C2;
-            const float inv = 1.0f / (B1 * B2);
-            const float S = A1 * A2 * inv;
-            ssum += S;
-            const size_t oo = ((size_t)plane * q.Hv + gy) * q.Wv + gx;
-            q.dm[oo] = 2.f * mu * (A2 - A1) * inv - 2.f * m * S / B1 + 2.f * m * S / B2;
-            q.dq[oo] = -S / B2;
-            q.dr[oo] = 2.f * A1 * inv;
+            const int i = r4 + o;
+            const int vy = y0 - 10 + i, vx = x0 - 10 + j;
+            float dm = 0.f, dq = 0.f, dr = 0.f;
+            if (vy >= 0 && vy < q.Hv && vx >= 0 && vx < q.Wv && j < F6_TW + 10) {
+                const float m = v[0][o], mu = v[1][o], qq = v[2][o], tt = v[3][o], rr = v[4][o];
+                const float sp = qq - m * m, st = tt - mu * mu, spt = rr - m * mu;
+                const float A1 = 2.f * m * mu + C1, A2 = 2.f * spt + C2;
+                const float B1 = m * m + mu * mu + C1, B2 = sp + st + C2;
+                const float inv = 1.0f / (B1 * B2);
+                const float S = A1 * A2 * inv;
+                if (i >= 10 && j >= 10 && (rg < 2 || o > 0)) ssum += S;      // this tile's own part of the map, once
+                dm = 2.f * mu * (A2 - A1) * inv - 2.f * m * S / B1 + 2.f * m * S / B2;
+                dq = -S / B2;
+                dr = 2.f * A1 * inv;
+            }
+            float *d = Dm + i * F6_DWP + j;
+            d[0] = dm; d[F6_DH * F6_DWP] = dq; d[2 * F6_DH * F6_DWP] = dr;      // X is dead since the barrier above
         }
     }
-    const float tot = orn_block_sum(ssum, sred);
-    if (t == 0) q.part_ssim[(size_t)plane * gridDim.x + blockIdx.x] = tot;
-}
-
-// LT / GRAD are compile-time: the per-pixel loop carries no loss-type or null-pointer branches
-template <int LT, bool GRAD>
-__global__ void __launch_bounds__(256) k_loss_grad(LossP q)
-{
-    __shared__ __attribute__((aligned(16))) float Ds[3][SS_PH][SS_PWP];
-    __shared__ __attribute__((aligned(16))) float Hh[3][SS_PH][SS_TW];
-    __shared__ float sred[16];
-    const int t = threadIdx.x;
-    const int plane = blockIdx.y;
-    const int tw = blockIdx.x % q.tiles_w, th = blockIdx.x / q.tiles_w;
-    const int y0 = th * SS_TH, x0 = tw * SS_TW;
-    const size_t HW = (size_t)q.H * q.W;
-    const float *pp = q.pred + (size_t)plane * HW;
-    const float *tp = q.target + (q.frame_idx ? (size_t)(*q.frame_idx) * q.frame_stride : 0) + (size_t)plane * HW;
-    constexpr bool ssim = (LT == ORN_LOSS_FUSION6);
-    if (ssim) {
-        const size_t mo = (size_t)plane * q.Hv * q.Wv;
-        {
-            constexpr int NL = (SS_PH * SS_PWP + 255) / 256;
-            float r0[NL], r1[NL], r2[NL];
-#pragma unroll
-            for (int it = 0; it < NL; ++it) {
-                const int idx = t + it * 256;
-                const int r = idx / SS_PWP, c = idx - r * SS_PWP;
-                const int vy = y0 + r - 10, vx = x0 + c - 10;       // valid-map coords
-                r0[it] = 0.f; r1[it] = 0.f; r2[it] = 0.f;
-                if (idx < SS_PH * SS_PWP && c < SS_PW && vy >= 0 && vy < q.Hv && vx >= 0 && vx < q.Wv) {
-                    const size_t o = mo + (size_t)vy * q.Wv + vx;
-                    r0[it] = q.dm[o]; r1[it] = q.dq[o]; r2[it] = q.dr[o];
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < NL; ++it) {
-                const int idx = t + it * 256;
-                if (idx < SS_PH * SS_PWP) { (&Ds[0][0][0])[idx] = r0[it]; (&Ds[1][0][0])[idx] = r1[it]; (&Ds[2][0][0])[idx] = r2[it]; }
-            }
-        }
-        __syncthreads();
-        // out[y][x] = sum_{a,b} g[a] g[b] D[y-a][x-b];  patch index of (y-a) is (y_local + 10 - a)
-        for (int idx = t; idx < SS_PH * (SS_TW / 4); idx += 256) {
-            const int r = idx / (SS_TW / 4), c4 = (idx - r * (SS_TW / 4)) * 4;
+    __syncthreads();
+    float sabs = 0.f, ssq = 0.f;
+    // ---- adjoint row filter: Hh[m][i][c] = sum_k g[k] D[m][i][c + 10 - k]; item = (row i, 4 columns, map m)
+    if (GRAD) {
+        for (int idx = t; idx < F6_DH * (F6_TW / 4); idx += 256) {
+            const int r = idx / (F6_TW / 4), c4 = (idx - r * (F6_TW / 4)) * 4;
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 float w[16];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float4 v = *reinterpret_cast<const float4 *>(&Ds[m][r][c4 + 4 * k]);
-                    w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+                    const float4 vv = *reinterpret_cast<const float4 *>(Dm + (m * F6_DH + r) * F6_DWP + c4 + 4 * k);
+                    w[4 * k] = vv.x; w[4 * k + 1] = vv.y; w[4 * k + 2] = vv.z; w[4 * k + 3] = vv.w;
                 }
                 float hv[4];
 #pragma unroll
@@ -196,11 +205,69 @@ __global__ void __launch_bounds__(256) k_loss_grad(LossP q)
                     for (int k = 0; k < 11; ++k) acc = fmaf(c_gauss[k], w[o + 10 - k], acc);
                     hv[o] = acc;
                 }
-                *reinterpret_cast<float4 *>(&Hh[m][r][c4]) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+                *reinterpret_cast<float4 *>(Hh + (m * F6_DH + r) * F6_TW + c4) = make_float4(hv[0], hv[1], hv[2], hv[3]);
             }
         }
         __syncthreads();
     }
+    // ---- adjoint column filter + L1 term: thread = (column c, 4 rows)
+    {
+        const int c = t & (F6_TW - 1), r4 = (t >> 6) * 4;
+        float am[4] = {0, 0, 0, 0}, aq[4] = {0, 0, 0, 0}, ar[4] = {0, 0, 0, 0};
+        if (GRAD) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                float col[14];
+#pragma unroll
+                for (int k = 0; k < 14; ++k) col[k] = Hh[(m * F6_DH + r4 + k) * F6_TW + c];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) acc = fmaf(c_gauss[k], col[o + 10 - k], acc);
+                    if (m == 0) am[o] = acc; else if (m == 1) aq[o] = acc; else ar[o] = acc;
+                }
+            }
+        }
+        const int gx = x0 + c;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int gy = y0 + r4 + o;
+            if (gy >= q.H || gx >= q.W) continue;
+            const size_t oo = (size_t)gy * q.W + gx;
+            const float p = pp[oo], tg = tp[oo], d = p - tg;
+            sabs += fabsf(d);
+            ssq = fmaf(d, d, ssq);
+            if (GRAD) {
+                float g = q.g_l1 * ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
+                g -= q.g_ssim * (am[o] + 2.f * p * aq[o] + tg * ar[o]);
+                q.dpred[(size_t)plane * HW + oo] = g;
+            }
+        }
+    }
+    const float ts = orn_block_sum(ssum, sred);
+    const float ta = orn_block_sum(sabs, sred);
+    const float tq = orn_block_sum(ssq, sred);
+    if (t == 0) {
+        const size_t bi = (size_t)plane * gridDim.x + blockIdx.x;
+        q.part_ssim[bi] = ts;
+        q.part_l1[2 * bi] = ta;
+        q.part_l1[2 * bi + 1] = tq;
+    }
+}
+
+// L1 / L2 losses (no SSIM term).  LT / GRAD are compile-time: the per-pixel loop carries no loss-type or null-pointer branches
+template <int LT, bool GRAD>
+__global__ void __launch_bounds__(256) k_loss_grad(LossP q)
+{
+    __shared__ float sred[16];
+    const int t = threadIdx.x;
+    const int plane = blockIdx.y;
+    const int tw = blockIdx.x % q.tiles_w, th = blockIdx.x / q.tiles_w;
+    const int y0 = th * SS_TH, x0 = tw * SS_TW;
+    const size_t HW = (size_t)q.H * q.W;
+    const float *pp = q.pred + (size_t)plane * HW;
+    const float *tp = q.target + (q.frame_idx ? (size_t)(*q.frame_idx) * q.frame_stride : 0) + (size_t)plane * HW;
     float sabs = 0.f, ssq = 0.f;
     for (int idx = t; idx < SS_TH * SS_TW; idx += 256) {
         const int r = idx / SS_TW, c = idx - r * SS_TW;
@@ -211,20 +278,9 @@ __global__ void __launch_bounds__(256) k_loss_grad(LossP q)
         sabs += fabsf(d);
         ssq = fmaf(d, d, ssq);
         if (GRAD) {
-            float g = 0.f;
+            float g;
             if (LT == ORN_LOSS_L2) g = q.g_l2 * d;
             else g = q.g_l1 * ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
-            if (ssim) {
-                float am = 0.f, aq = 0.f, ar = 0.f;
-#pragma unroll
-                for (int k = 0; k < 11; ++k) {
-                    const float gk = c_gauss[k];
-                    am = fmaf(gk, Hh[0][r + 10 - k][c], am);
-                    aq = fmaf(gk, Hh[1][r + 10 - k][c], aq);
-                    ar = fmaf(gk, Hh[2][r + 10 - k][c], ar);
-                }
-                g -= q.g_ssim * (am + 2.f * p * aq + tg * ar);
-            }
             q.dpred[(size_t)plane * HW + o] = g;
         }
     }
@@ -299,29 +355,37 @@ static int ensure_gauss()
     return 0;
 }
 
-// Must be called once outside any graph capture (hipMemcpyToSymbol is synchronous).
-int orn_loss_init() { return ensure_gauss(); }
+struct LossGeom { int planes, Hv, Wv, tw, th; size_t nmap, off_pl, total; };
 
-struct LossGeom { int planes, Hv, Wv, twv, thv, tw, th; size_t nmap, off_dq, off_dr, off_ps, off_pl, total; };
-
+// one tiling (16 x 64 pixels of the image) for every loss type; per-tile partial sums: SSIM [n], {|d|, d^2} [n][2]
 static LossGeom loss_geom(int B, int Ch, int H, int W)
 {
     LossGeom g;
     g.planes = B * Ch;
     g.Hv = H > 10 ? H - 10 : 0;
     g.Wv = W > 10 ? W - 10 : 0;
-    g.twv = orn_cdiv(g.Wv, SS_TW); g.thv = orn_cdiv(g.Hv, SS_TH);
     g.tw = orn_cdiv(W, SS_TW); g.th = orn_cdiv(H, SS_TH);
     g.nmap = (size_t)g.planes * g.Hv * g.Wv;
-    const size_t a = orn_align(g.nmap * 4) / 4;
-    g.off_dq = a; g.off_dr = 2 * a;
-    g.off_ps = 3 * a;
-    g.off_pl = g.off_ps + orn_align((size_t)g.planes * g.twv * g.thv * 4 + 4) / 4;
+    g.off_pl = orn_align((size_t)g.planes * g.tw * g.th * 4 + 4) / 4;
     g.total = g.off_pl + orn_align((size_t)g.planes * g.tw * g.th * 8 + 8) / 4;
     return g;
 }
 
 extern "C" size_t orn_loss_ws_bytes(int B, int Ch, int H, int W) { return loss_geom(B, Ch, H, W).total * 4; }
+
+static int ensure_fusion6_lds()
+{
+    static bool done = false;
+    if (done) return 0;
+    hipError_t e = hipFuncSetAttribute((const void *)k_fusion6<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F6_LDS_FLOATS * 4);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_fusion6<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F6_LDS_FLOATS * 4);
+    if (e != hipSuccess) { orn_set_error("loss: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    done = true;
+    return 0;
+}
+
+// Must be called once outside any graph capture (hipMemcpyToSymbol is synchronous).
+int orn_loss_init() { ORN_TRY(ensure_gauss()); return ensure_fusion6_lds(); }
 
 int orn_launch_loss(const float *pred, const float *target, const int *frame_idx, size_t frame_stride, int B, int Ch,
                     int H, int W, int loss_type, float loss_scale, float *stats, float *dpred, float *ws,
@@ -329,35 +393,33 @@ int orn_launch_loss(const float *pred, const float *target, const int *frame_idx
 {
     ORN_REQUIRE(loss_type == ORN_LOSS_L2 || loss_type == ORN_LOSS_L1 || loss_type == ORN_LOSS_FUSION6,
                 "loss: unsupported loss_type %d", loss_type);
-    ORN_TRY(ensure_gauss());
+    ORN_TRY(orn_loss_init());
+    static_assert(SS_TH == F6_TH && SS_TW == F6_TW, "one tiling for all loss kernels");
     const LossGeom g = loss_geom(B, Ch, H, W);
     if (loss_type == ORN_LOSS_FUSION6) ORN_REQUIRE(g.Hv > 0 && g.Wv > 0, "loss: SSIM needs H,W > 10 (got %dx%d)", H, W);
     LossP q;
     q.pred = pred; q.target = target; q.frame_idx = frame_idx; q.frame_stride = frame_stride;
     q.planes = g.planes; q.H = H; q.W = W; q.Hv = g.Hv; q.Wv = g.Wv;
-    q.dm = ws; q.dq = ws + g.off_dq; q.dr = ws + g.off_dr;
-    q.part_ssim = ws + g.off_ps; q.part_l1 = ws + g.off_pl;
+    q.part_ssim = ws; q.part_l1 = ws + g.off_pl;
     q.dpred = dpred; q.loss_type = loss_type;
+    q.vec4 = (W % 4 == 0 && ((uintptr_t)pred | (uintptr_t)target) % 16 == 0 && (frame_stride % 4 == 0 || !frame_idx)) ? 1 : 0;
     const double n = (double)g.planes * H * W;
     q.g_l1 = (float)((loss_type == ORN_LOSS_FUSION6 ? 0.7 : 1.0) * loss_scale / n);
     q.g_l2 = (float)(2.0 * loss_scale / n);
     q.g_ssim = g.nmap ? (float)(0.3 * loss_scale / (double)g.nmap) : 0.f;
-    q.tiles_w_v = g.twv; q.tiles_h_v = g.thv; q.tiles_w = g.tw; q.tiles_h = g.th;
-    int n_ssim = 0;
-    if (loss_type == ORN_LOSS_FUSION6) {
-        n_ssim = g.planes * g.twv * g.thv;
-        hipLaunchKernelGGL(k_ssim_stats, dim3(g.twv * g.thv, g.planes), dim3(256), 0, st, q);
-        ORN_LAUNCH_CHECK("ssim_stats");
-    }
+    q.tiles_w = g.tw; q.tiles_h = g.th;
+    const int n_tiles = g.planes * g.tw * g.th;
     {
         const dim3 gr(g.tw * g.th, g.planes), bl(256);
         const bool gd = q.dpred != nullptr;
-        if (loss_type == ORN_LOSS_FUSION6) { if (gd) hipLaunchKernelGGL((k_loss_grad<ORN_LOSS_FUSION6, true>), gr, bl, 0, st, q); else hipLaunchKernelGGL((k_loss_grad<ORN_LOSS_FUSION6, false>), gr, bl, 0, st, q); }
+        if (loss_type == ORN_LOSS_FUSION6) {
+            if (gd) hipLaunchKernelGGL((k_fusion6<true>), gr, bl, F6_LDS_FLOATS * 4, st, q); else hipLaunchKernelGGL((k_fusion6<false>), gr, bl, F6_LDS_FLOATS * 4, st, q);
+        }
         else if (loss_type == ORN_LOSS_L2) { if (gd) hipLaunchKernelGGL((k_loss_grad<ORN_LOSS_L2, true>), gr, bl, 0, st, q); else hipLaunchKernelGGL((k_loss_grad<ORN_LOSS_L2, false>), gr, bl, 0, st, q); }
         else { if (gd) hipLaunchKernelGGL((k_loss_grad<ORN_LOSS_L1, true>), gr, bl, 0, st, q); else hipLaunchKernelGGL((k_loss_grad<ORN_LOSS_L1, false>), gr, bl, 0, st, q); }
     }
-    ORN_LAUNCH_CHECK("loss_grad");
-    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, st, q.part_ssim, n_ssim, q.part_l1, g.planes * g.tw * g.th, n,
+    ORN_LAUNCH_CHECK("loss");
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, st, q.part_ssim, loss_type == ORN_LOSS_FUSION6 ? n_tiles : 0, q.part_l1, n_tiles, n,
                        (double)g.nmap, loss_type, loss_scale, stats, cur, ring, sc);
     ORN_LAUNCH_CHECK("loss_finalize");
     return 0;

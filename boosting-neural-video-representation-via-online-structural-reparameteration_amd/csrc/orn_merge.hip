@@ -6,6 +6,8 @@
 // oracle/merge_ref.c specifies -- so the forward is bit-exact against the CPU oracle.
 #include "orn_internal.h"
 #include "orn_merge_pack.h"
+#include <cstdlib>
+#include <type_traits>
 
 struct GemmP {
     const float *A, *B;
@@ -16,6 +18,7 @@ struct GemmP {
     long scm, scn;   // C(m,n) = C[m*scm + n*scn]
     long ba, bb, bc; // per-batch element offsets (blockIdx.z)
     int a_kfast, b_nfast;
+    int a_vec, b_vec;    // gemm_body2: 16-byte global loads of A along k / of B along n are possible (strides, sizes and bases aligned)
     // epilogue 1 (merge combine): C = (w3x3 + (P(w1x3) + P(w3x1))) + acc, n = c*9 + ij
     int epi;
     const float *w3x3, *w1x3, *w3x1;
@@ -146,6 +149,281 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, int bx, int by, int bz
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Round 3 forward-merge GEMM (B(k,n) contiguous in n; A any strides): same arithmetic as gemm_body -- one k-ordered fmaf
+// chain per output on v_mfma_f32_32x32x2_f32, bit-identical to oracle/merge_ref.c -- rebuilt around its latency chain:
+//   * K chunks of 32, two LDS stages, ONE barrier per chunk; the global loads of chunk i+2 are issued before the MFMAs of
+//     chunk i and stored to LDS right after the next barrier (a whole chunk of MFMAs to land in);
+//   * 16-byte global loads wherever rows are 16-byte aligned (W3, T and W1 of the C = 96 layers), clamped scalar loads
+//     otherwise (W2 is read with its stride of 9 floats);
+//   * A is kept [row][k] in LDS (16-byte chunks XOR-swizzled with (row >> 1) & 7: conflict-free ds_read_b128); a lane reads
+//     the 4 k of two consecutive MFMA steps at once and picks its half's element (k = 2 s + (lane >> 5)) with one select;
+//   * work-group tile = (32 WM) x (32 WN): 2x2 waves for the S products, 4x1 for the T products (N = C = 96 or 26 columns).
+#define G2_KC 32
+template <int WM, int WN>
+struct G2Regs { float4 a[WM], b[WN]; };
+
+#ifdef ORN_MERGE_STAMP
+// Diagnostic build only (tools/probes/merge_stamps.py): s_memtime phase sums of work-group (0,0,0), wave 0.
+// [0] whole kernel  [1] prologue  [2] K loop  [3] epilogue  [4] sum LDS store (incl. the wait for its global loads)
+// [5] sum global-load issue + barrier  [6] sum fragment-read issue + MFMAs  [8] chunks
+__device__ unsigned long long g_mst[16];
+extern "C" __attribute__((visibility("default"))) int orn_debug_merge_stamps(unsigned long long *out16)
+{
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_mst), sizeof(g_mst));
+}
+#define MST_NOW(t_) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define MST_NOW(t_) do { } while (0)
+#endif
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N)
+template <int I, int N, class F>
+__device__ __forceinline__ void g2_sfor(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        g2_sfor<I + 1, N>(f);
+    }
+}
+
+template <int WM, int WN, bool AVEC, bool BVEC>
+__device__ __forceinline__ void gemm_body2v(const GemmP &p, int bx, int by, int bz, float *lds)
+{
+    constexpr int BM = 32 * WM, BN = 32 * WN;
+    // one LDS stage: A as two blocks [k parity][BM rows][16 floats] (a lane half of the 32x32x2 MFMA consumes one parity:
+    // k = 2 s + (lane >> 5), so its 4 floats of a 16-byte read are the operands of 4 consecutive MFMA steps -- no per-step
+    // select), 16-byte chunks XOR-swizzled with (row >> 2) & 3 (conflict-free ds_read_b128); then B [32 k][BN]
+    constexpr int STAGE = BM * G2_KC + G2_KC * BN;
+    constexpr int BCH = BN / 4;                               // 16-byte chunks per B row
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int m0 = by * BM, n0 = bx * BN;
+    const float *A = p.A + (long)bz * p.ba;
+    const float *B = p.B + (long)bz * p.bb;
+    float *C = p.C + (long)bz * p.bc;
+    const int M = p.M, N = p.N, K = p.K;
+    const int sam = (int)p.sam, sak = (int)p.sak, sbk = (int)p.sbk;
+    constexpr bool avec = AVEC, bvec = BVEC;       // compile-time: behind a runtime flag hipcc merges the two load forms into 4 dword loads
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // staging units: A unit u = t + 256 i -> (row u >> 3, 4 k from 4 (u & 7)); B unit u -> (k row u / BCH, 4 n from 4 (u % BCH))
+    int a_row[WM], a_ch[WM], b_kr[WN], b_ch[WN];
+    unsigned a_base[WM], b_col[WN][4];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int u = t + 256 * i;
+        a_row[i] = u >> 3; a_ch[i] = u & 7;
+        a_base[i] = (unsigned)__mul24(min(m0 + a_row[i], M - 1), sam);
+    }
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+        const int u = t + 256 * i;
+        b_kr[i] = u / BCH; b_ch[i] = u - b_kr[i] * BCH;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b_col[i][j] = (unsigned)min(n0 + 4 * b_ch[i] + (bvec ? 0 : j), N - (bvec ? 4 : 1));
+    }
+    G2Regs<WM, WN> R;
+    // clamped loads: rows / columns beyond the edge re-read the last valid one (never stored), k beyond K the last valid k
+    // (replaced by +0.0f on its way into LDS: fma(0, 0, acc) == acc keeps the chain exact)
+    auto gload_a = [&](int i, int k0) {
+        const int k = k0 + 4 * a_ch[i];
+        if constexpr (avec) {
+            R.a[i] = *reinterpret_cast<const float4 *>(A + (a_base[i] + (unsigned)min(k, K - 4)));
+        } else {
+            R.a[i].x = A[a_base[i] + (unsigned)__mul24(min(k, K - 1), sak)];
+            R.a[i].y = A[a_base[i] + (unsigned)__mul24(min(k + 1, K - 1), sak)];
+            R.a[i].z = A[a_base[i] + (unsigned)__mul24(min(k + 2, K - 1), sak)];
+            R.a[i].w = A[a_base[i] + (unsigned)__mul24(min(k + 3, K - 1), sak)];
+        }
+    };
+    auto gload_b = [&](int i, int k0) {
+        const unsigned kb = (unsigned)__mul24(min(k0 + b_kr[i], K - 1), sbk);
+        if constexpr (bvec) {
+            R.b[i] = *reinterpret_cast<const float4 *>(B + (kb + b_col[i][0]));
+        } else {
+            R.b[i].x = B[kb + b_col[i][0]];
+            R.b[i].y = B[kb + b_col[i][1]];
+            R.b[i].z = B[kb + b_col[i][2]];
+            R.b[i].w = B[kb + b_col[i][3]];
+        }
+    };
+    auto lstore_a = [&](int i, int k0, float *st) {
+        const int k = k0 + 4 * a_ch[i], row = a_row[i];
+        const float4 v = R.a[i];
+        float *d = st + row * 16 + 4 * ((a_ch[i] >> 1) ^ ((row >> 2) & 3)) + 2 * (a_ch[i] & 1);
+        *reinterpret_cast<float2 *>(d) = make_float2(k < K ? v.x : 0.f, k + 2 < K ? v.z : 0.f);                 // even k
+        *reinterpret_cast<float2 *>(d + BM * 16) = make_float2(k + 1 < K ? v.y : 0.f, k + 3 < K ? v.w : 0.f);   // odd k
+    };
+    auto lstore_b = [&](int i, int k0, float *st) {
+        const bool ok = k0 + b_kr[i] < K;
+        float4 v = R.b[i];
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+        *reinterpret_cast<float4 *>(st + BM * G2_KC + b_kr[i] * BN + 4 * b_ch[i]) = v;
+    };
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) gload_a(i, k0);
+#pragma unroll
+        for (int i = 0; i < WN; ++i) gload_b(i, k0);
+    };
+    auto lstore = [&](int k0, float *st) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) lstore_a(i, k0, st);
+#pragma unroll
+        for (int i = 0; i < WN; ++i) lstore_b(i, k0, st);
+    };
+    // Software pipeline over the K chunks, three LDS stages (chunk c lives in stage c % 3), two fragment register sets:
+    //   iteration i:  fragment reads of chunk i+1 -> the other set | 16 MFMAs of chunk i from this set, and BETWEEN them
+    //                 (a wave is in-order: what is written behind the chain starts when the chain has issued) chunk i+2
+    //                 -> LDS, then the global loads of chunk i+3 | barrier
+    // so the LDS round trip of chunk i+1 and the staging traffic of the later chunks sit under the MFMA chain of chunk i
+    // (a wave has no partner on its SIMD in these launches: ~1.2 waves per SIMD chip-wide).  What the barrier at the end of
+    // iteration i orders: chunk i+2 visible to the reads of iteration i+1; the reads of chunk i (finished before its MFMAs)
+    // before chunk i+3 overwrites their stage in iteration i+1.  The chunk count is rounded up to even (a chunk behind K is
+    // all zeros), so the unrolled pair has no exit in the middle.
+    struct Frag { float4 a4[G2_KC / 8]; float b[G2_KC / 2]; };
+    const int arow = wm * 32 + l31;
+    const int a_rd = hh * (BM * 16) + arow * 16, a_sw = (arow >> 2) & 3;
+    auto fread = [&](Frag &F, const float *st) {
+        const float *ap = st + a_rd;
+        const float *bp = st + BM * G2_KC + hh * BN + wn * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < G2_KC / 8; ++j) F.a4[j] = *reinterpret_cast<const float4 *>(ap + 4 * (j ^ a_sw));
+#pragma unroll
+        for (int s2 = 0; s2 < G2_KC / 2; ++s2) F.b[s2] = bp[(2 * s2) * BN];
+    };
+    const int nreal = (K + G2_KC - 1) / G2_KC, nch = (nreal + 1) & ~1;
+    Frag FX, FY;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, ta = 0, tb = 0, s6 = 0;
+    (void)t0; (void)t1; (void)t2; (void)ta; (void)tb; (void)s6;
+    MST_NOW(t0);
+    gload(0);
+    __syncthreads();                                       // the LDS block may still be in use by a previous role of this array
+    lstore(0, lds);
+    gload(G2_KC);
+    __syncthreads();
+    fread(FX, lds);                                        // chunk 0
+    lstore(G2_KC, lds + STAGE);                            // chunk 1 (zeros if it lies behind K)
+    gload(2 * G2_KC);
+    __syncthreads();
+    MST_NOW(t1);
+    int sB = 1, sC = 2;                                    // stages of chunks i+1, i+2
+    constexpr int NPC = WM + WN;                           // staging pieces per chunk: stores ride MFMA pairs 0..3, loads pairs 4..7
+    auto step = [&](Frag &Fcur, Frag &Fnext, int i) {
+        MST_NOW(ta);
+        // No conditions on the chunk index in here: the step is ONE basic block (behind per-piece branches hipcc's wait
+        // insertion put vmcnt(0) in front of every load, i.e. one L2 round trip per load).  Chunks behind K are read with
+        // clamped addresses and stored as zeros into stages nobody reads any more; the reads behind the last chunk are unused.
+        fread(Fnext, lds + sB * STAGE);
+        __builtin_amdgcn_sched_barrier(0);                 // (the scheduler otherwise sinks these reads behind the MFMAs that should cover them)
+        float *dst = lds + sC * STAGE;
+        const int k_st = (i + 2) * G2_KC, k_ld = (i + 3) * G2_KC;
+        g2_sfor<0, G2_KC / 4>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Fcur.a4[q >> 1][2 * (q & 1)], Fcur.b[2 * q], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Fcur.a4[q >> 1][2 * (q & 1) + 1], Fcur.b[2 * q + 1], acc, 0, 0, 0);
+            g2_sfor<0, NPC>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (q < 4 && j * 4 / NPC == q) {
+                    if constexpr (j < WM) lstore_a(j, k_st, dst); else lstore_b(j - WM, k_st, dst);
+                }
+                if constexpr (q >= 4 && 4 + j * 4 / NPC == q) {
+                    if constexpr (j < WM) gload_a(j, k_ld); else gload_b(j - WM, k_ld);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);             // pins the interleave: two MFMAs, then this pair's staging piece(s)
+        });
+        __syncthreads();
+        MST_NOW(tb);
+#ifdef ORN_MERGE_STAMP
+        s6 += tb - ta;
+#endif
+        const int tmp = sB; sB = sC; sC = (tmp + 2) % 3;   // stages rotate: (i+1, i+2) -> (i+2, i+3)
+    };
+    for (int i = 0; i < nch; i += 2) {
+        step(FX, FY, i);
+        step(FY, FX, i + 1);
+    }
+    MST_NOW(t2);
+    const int gn = n0 + wn * 32 + l31;
+    if (p.epi == 1 && p.bf && bx == 0 && wn == 0 && l31 == 0) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int gm = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+            if (gm < p.M) {
+                const float b = p.b3x3[gm] + (p.b1x3[gm] + p.b3x1[gm]);     // model.py:476,496
+                p.bf[gm] = b;
+                if (p.half_kind) p.biasp[(gm % p.s2) * p.Cn + gm / p.s2] = b;
+            }
+        }
+    }
+    if (gn < p.N) {
+    if (p.epi == 1) {
+        // the branch terms of all 16 rows first (48 independent loads in flight), then the stores: interleaved per row, every
+        // row's loads wait behind the previous row's stores (they may alias as far as the compiler knows) -- 16 dependent
+        // global round trips, ~4 us of a tile's ~15
+        const int c = gn / 9, ij = gn - c * 9, ii = ij / 3, jj = ij - ii * 3;
+        float base[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int gm = min(m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh, p.M - 1);
+            const long oc = (long)gm * p.Cch + c;
+            const float p13 = (ii == 1) ? p.w1x3[oc * 3 + jj] : 0.f;
+            const float p31 = (jj == 1) ? p.w3x1[oc * 3 + ii] : 0.f;
+            base[reg] = p.w3x3[(long)gm * p.N + gn] + (p13 + p31);          // association of model.py:475,495
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int gm = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+            if (gm >= p.M) continue;
+            const float r = base[reg] + acc[reg];
+            if (p.half_kind) {
+                const int op = (gm % p.s2) * p.Cn + gm / p.s2;
+                const size_t ib = ((size_t)ij * p.M + op) * p.Cp + c, id = ((size_t)(8 - ij) * p.Cp + c) * p.M + op;
+                if (p.half_kind == 1) {
+                    const __bf16 h = (__bf16)r;
+                    reinterpret_cast<__bf16 *>(p.wb)[ib] = h;
+                    reinterpret_cast<__bf16 *>(p.wd)[id] = h;
+                } else {
+                    const _Float16 h = (_Float16)r;
+                    reinterpret_cast<_Float16 *>(p.wb)[ib] = h;
+                    reinterpret_cast<_Float16 *>(p.wd)[id] = h;
+                }
+            }
+            C[(long)gm * p.scm + (long)gn * p.scn] = r;
+        }
+    } else {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int gm = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+            if (gm < p.M) C[(long)gm * p.scm + (long)gn * p.scn] = acc[reg];
+        }
+    }
+    }
+#ifdef ORN_MERGE_STAMP
+    {
+        unsigned long long t3;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MST_NOW(t3);
+        if (bx == 0 && by == 0 && bz == 0 && t == 0) {
+            g_mst[0] = t3 - t0; g_mst[1] = t1 - t0; g_mst[2] = t2 - t1; g_mst[3] = t3 - t2;
+            g_mst[4] = 0; g_mst[5] = 0; g_mst[6] = s6; g_mst[7] = 0; g_mst[8] = nch;
+        }
+    }
+#endif
+}
+#define G2_LDS_FLOATS (3 * (128 * G2_KC + G2_KC * 32))      // three stages of the larger of the two tile shapes (4x1): 60 KB
+template <int WM, int WN>
+__device__ __forceinline__ void gemm_body2(const GemmP &p, int bx, int by, int bz, float *lds)
+{
+    if (p.a_vec) { if (p.b_vec) gemm_body2v<WM, WN, true, true>(p, bx, by, bz, lds); else gemm_body2v<WM, WN, true, false>(p, bx, by, bz, lds); }
+    else         { if (p.b_vec) gemm_body2v<WM, WN, false, true>(p, bx, by, bz, lds); else gemm_body2v<WM, WN, false, false>(p, bx, by, bz, lds); }
+}
+
 // Same tiling on v_mfma_f32_32x32x16_f16 (fp32 accumulate): operands are rounded to IEEE half while they are
 // staged into LDS ([row][k], k contiguous, 144-byte rows: conflict-free ds_read_b128).  Used for the merge BACKWARD
 // in the 16-bit engine modes only -- the forward merge stays exact fp32.
@@ -216,6 +494,12 @@ __device__ __forceinline__ void gemm_body_h16(const GemmP &p, int bx, int by, in
 }
 
 __global__ void __launch_bounds__(256) k_gemm_f32(GemmP p) { gemm_body(p, blockIdx.x, blockIdx.y, blockIdx.z); }
+// forward products (B contiguous in n) on the round-3 body, 64x64 tiles
+__global__ void __launch_bounds__(256) k_gemm2_f32(GemmP p)
+{
+    __shared__ __attribute__((aligned(16))) float lds[G2_LDS_FLOATS];
+    gemm_body2<2, 2>(p, blockIdx.x, blockIdx.y, blockIdx.z, lds);
+}
 
 // Grouped form: several independent problems in one launch (the engine merges all layers at once so
 // the small per-layer GEMMs fill the chip together).  The table lives in device memory.
@@ -223,6 +507,7 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmP p) { gemm_body(p, blockI
 struct GemmGroup {
     int n;
     int h16;                    // 1: problems run on the 16-bit MFMA variant
+    int shape;                  // k_gemm_f32_grouped_linear: 0 = 64x64 tiles (2x2 waves), 1 = 128x32 tiles (4x1 waves)
     int tile_start[GEMM_MAXP + 1];
     GemmP prob[GEMM_MAXP];
 };
@@ -245,13 +530,14 @@ __global__ void __launch_bounds__(256) k_gemm_f32_grouped(const GemmGroup *__res
 __global__ void __launch_bounds__(256) k_gemm_f32_grouped_linear(const GemmGroup *__restrict__ g, OrnLinearJob job, int gemm_tiles, int lin_blocks,
                                                                  MhPackAll pack)
 {
-    // the GEMM tiles are the long latency chains: they are dispatched first, the short work-groups behind them: the stem's
-    // linear layer, then (16-bit engine modes, S launch) the parameter-side half copies of the merge BACKWARD's operands
+    __shared__ __attribute__((aligned(16))) float lds[G2_LDS_FLOATS];      // one array for every role of the launch
+    // the GEMM tiles are the long latency chains: they are dispatched first (largest K first), the short work-groups behind
+    // them: the stem's linear layer, then (16-bit engine modes, S launch) the parameter-side half copies of the merge
+    // BACKWARD's operands
     if ((int)blockIdx.x >= gemm_tiles + lin_blocks) {
-        __shared__ float tile[64][65];
         int layer, pjob;
         const int blk = mh_pack_decode(pack, true, (int)blockIdx.x - gemm_tiles - lin_blocks, layer, pjob);
-        mh_pack_block(pack, layer, pjob, blk, tile);
+        mh_pack_block(pack, layer, pjob, blk, reinterpret_cast<float (*)[65]>(lds));
         return;
     }
     if ((int)blockIdx.x >= gemm_tiles) {
@@ -263,20 +549,31 @@ __global__ void __launch_bounds__(256) k_gemm_f32_grouped_linear(const GemmGroup
     while (pi + 1 < g->n && bid >= g->tile_start[pi + 1]) ++pi;
     const GemmP p = g->prob[pi];
     const int local = bid - g->tile_start[pi];
-    const int tn = (p.N + GT - 1) / GT, tm = (p.M + GT - 1) / GT;
-    const int bz = local / (tn * tm), rem = local - bz * tn * tm;
-    gemm_body(p, rem % tn, rem / tn, bz);
+    if (g->shape == 1) {
+        const int tn = (p.N + 31) / 32, tm = (p.M + 127) / 128;
+        const int bz = local / (tn * tm), rem = local - bz * tn * tm;
+        gemm_body2<4, 1>(p, rem % tn, rem / tn, bz, lds);
+    } else {
+        const int tn = (p.N + 63) / 64, tm = (p.M + 63) / 64;
+        const int bz = local / (tn * tm), rem = local - bz * tn * tm;
+        gemm_body2<2, 2>(p, rem % tn, rem / tn, bz, lds);
+    }
 }
 
 static void finish_gemm(GemmP &p)
 {
     p.a_kfast = (labs(p.sak) <= labs(p.sam)) ? 1 : 0;
     p.b_nfast = (labs(p.sbn) <= labs(p.sbk)) ? 1 : 0;
+    p.a_vec = (p.sak == 1 && p.sam % 4 == 0 && p.K % 4 == 0 && p.K >= 4 && p.ba % 4 == 0 && (uintptr_t)p.A % 16 == 0) ? 1 : 0;
+    p.b_vec = (p.sbn == 1 && p.sbk % 4 == 0 && p.N % 4 == 0 && p.N >= 4 && p.bb % 4 == 0 && (uintptr_t)p.B % 16 == 0) ? 1 : 0;
 }
 
 static int launch_gemm(GemmP p, int batch, hipStream_t st, const char *name)
 {
     finish_gemm(p);
+    static const bool old_body = getenv("ORN_MERGE_OLD_BODY") != nullptr;      // probe switch (tools/probes/merge_probe.py)
+    if (p.sbn == 1 && !old_body) hipLaunchKernelGGL(k_gemm2_f32, dim3(orn_cdiv(p.N, GT), orn_cdiv(p.M, GT), batch), dim3(256), 0, st, p);
+    else
     hipLaunchKernelGGL(k_gemm_f32, dim3(orn_cdiv(p.N, GT), orn_cdiv(p.M, GT), batch), dim3(256), 0, st, p);
     ORN_LAUNCH_CHECK(name);
     return 0;
@@ -452,7 +749,7 @@ extern "C" int orn_erb_merge_bwd(const float *g, const float *dbf, const float *
 static void group_add(GemmGroup &g, GemmP p, int batch)
 {
     finish_gemm(p);
-    const int tiles = orn_cdiv(p.N, GT) * orn_cdiv(p.M, GT) * batch;
+    const int tiles = (g.shape == 1 ? orn_cdiv(p.N, 32) * orn_cdiv(p.M, 128) : orn_cdiv(p.N, GT) * orn_cdiv(p.M, GT)) * batch;
     g.prob[g.n] = p;
     g.tile_start[g.n + 1] = g.tile_start[g.n] + tiles;
     ++g.n;
@@ -465,6 +762,7 @@ int orn_merge_groups_build(void *dev_tables, int n_layers, const OrnMergeLayer *
 {
     ORN_REQUIRE(2 * n_layers <= GEMM_MAXP, "merge groups: too many layers");
     GemmGroup *h = new GemmGroup[4]();
+    h[0].shape = 1;             // T products: N = C columns -> 128x32 tiles
     for (int i = 0; i < n_layers; ++i) {
         const OrnMergeLayer &l = L[i];
         group_add(h[0], prob_T(l.w1, l.w2, l.C, l.O, l.T), 9);
@@ -495,7 +793,7 @@ int orn_merge_group_tiles(int which, int n_layers, const OrnMergeLayer *L)
     for (int i = 0; i < n_layers; ++i) {
         const int C = L[i].C, O = L[i].O, n = C * 9, K2 = 2 * C;
         switch (which) {
-        case 0: t += orn_cdiv(C, GT) * orn_cdiv(O, GT) * 9; break;
+        case 0: t += orn_cdiv(C, 32) * orn_cdiv(O, 128) * 9; break;
         case 1: t += orn_cdiv(n, GT) * orn_cdiv(O, GT); break;
         case 2: t += orn_cdiv(O, GT) * orn_cdiv(O, GT) + orn_cdiv(n, GT) * orn_cdiv(O, GT); break;
         default: t += orn_cdiv(K2, GT) * orn_cdiv(O, GT) * 9 + orn_cdiv(C, GT) * orn_cdiv(K2, GT) * 9; break;
@@ -517,9 +815,12 @@ int orn_launch_merge_group_linear(const void *dev_tables, int which, int tiles, 
                                   int pack_blocks)
 {
     const GemmGroup *g = (const GemmGroup *)dev_tables + which;
-    const int lin_blocks = orn_cdiv(job.N, 4);
+    int lin_blocks = orn_cdiv(job.N, 4);
     MhPackAll pk = {};
     if (pack && pack_blocks > 0) pk = *(const MhPackAll *)pack; else pack_blocks = 0;
+    static const int dbg = getenv("ORN_MERGE_DBG") ? atoi(getenv("ORN_MERGE_DBG")) : 0;      // probe switch: timing only, results WRONG
+    if (dbg & 1) pack_blocks = 0;
+    if (dbg & 2) lin_blocks = 0;
     hipLaunchKernelGGL(k_gemm_f32_grouped_linear, dim3(tiles + lin_blocks + pack_blocks), dim3(256), 0, st, g, job, tiles, lin_blocks, pk);
     ORN_LAUNCH_CHECK("merge_group_linear");
     return 0;

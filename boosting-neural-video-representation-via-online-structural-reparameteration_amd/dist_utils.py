@@ -1,10 +1,16 @@
 """Multi-GPU plumbing: independent per-video fits, one per rank.  The data path has no
 collective; torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests)
 is used only for the barrier, the max-over-ranks wall time and the end-of-run result gather."""
+import datetime
 import os
 from typing import Dict, List, Sequence
 
 import torch
+
+# Ranks fit different videos and meet only in the end-of-job gather: a rank with fewer or shorter videos waits there for the
+# slowest one, for as long as a whole fit takes.  torch's default collective timeout (10 min for NCCL) would abort it -- and
+# with it every rank still fitting -- so the group gets a timeout no fit reaches (ORN_DIST_TIMEOUT_S overrides it).
+DEFAULT_TIMEOUT_S = 7 * 24 * 3600
 
 
 def env_world():
@@ -20,7 +26,7 @@ def shard_videos(n_videos: int, world: int, rank: int) -> List[int]:
     return list(range(rank, n_videos, world))
 
 
-def init(backend: str = None):
+def init(backend: str = None, timeout_s: float = None):
     """init_process_group from the environment; returns the module or None for a single process."""
     rank, _, world = env_world()
     if world <= 1:
@@ -28,8 +34,11 @@ def init(backend: str = None):
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
+    if timeout_s is None:
+        timeout_s = float(os.environ.get('ORN_DIST_TIMEOUT_S', DEFAULT_TIMEOUT_S))
     if not dist.is_initialized():
-        dist.init_process_group(backend or ('nccl' if torch.cuda.is_available() else 'gloo'), rank=rank, world_size=world)
+        dist.init_process_group(backend or ('nccl' if torch.cuda.is_available() else 'gloo'), rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=timeout_s))
     return dist
 
 
@@ -43,7 +52,7 @@ def max_over_ranks(dist, seconds: float, device='cpu') -> float:
 
 
 def gather_records(dist, record: Sequence[float], device='cpu') -> List[List[float]]:
-    """all_gather of one small per-rank record [psnr, ms-ssim, frames, seconds, steps] (20 B/rank)."""
+    """all_gather of one small per-rank record [psnr sum over its videos, videos fitted, frames, seconds, steps] (20 B/rank)."""
     rec = torch.tensor(list(record), dtype=torch.float32, device=device)
     if dist is None:
         return [rec.tolist()]
@@ -53,7 +62,9 @@ def gather_records(dist, record: Sequence[float], device='cpu') -> List[List[flo
 
 
 def aggregate(records: List[List[float]], job_seconds: float) -> Dict[str, float]:
-    """Whole-job numbers from the gathered records: total frames/s over the slowest rank's time."""
+    """Whole-job numbers from the gathered records: total frames/s over the slowest rank's time; the PSNR is the mean over
+    the VIDEOS of the job (a rank without a video contributes nothing to it)."""
     frames = sum(r[2] for r in records)
+    videos = sum(r[1] for r in records)
     return {'frames_per_s': frames / job_seconds if job_seconds > 0 else 0.0,
-            'mean_psnr': sum(r[0] for r in records) / len(records), 'ranks': len(records)}
+            'mean_psnr': sum(r[0] for r in records) / videos if videos > 0 else 0.0, 'videos': int(videos), 'ranks': len(records)}

@@ -22,7 +22,7 @@ ERB_BRANCHES = ('rbr_3x3_branch', 'rbr_3x1_branch', 'rbr_1x3_branch', 'rbr_1x1_3
                 'rbr_1x1_3x3_1x1_branch_3x3', 'rbr_1x1_3x3_1x1_branch_1x1_2')
 
 
-def _prune_finetune(model, args, PE, ckpt_path):
+def _prune_finetune(model, args, PE, ckpt_path, vid_index=0):
     """main_eval.py:213-531 on the native engine (see the module docstring for the reference quirks kept)."""
     from . import engine as oeng
     named = dict(model.named_parameters())
@@ -52,7 +52,7 @@ def _prune_finetune(model, args, PE, ckpt_path):
     eng.set_grad_mask(gmask)
     hw = eng.out_hw
     from .main_train import load_frames
-    frames, pos = load_frames(args, hw, eng.device, args.dataset, 0, args.frame_gap)
+    frames, pos = load_frames(args, hw, eng.device, args.dataset, vid_index, args.frame_gap)
     n = frames.shape[0]
     eng.set_video(frames, PE(pos))
     try:
@@ -87,9 +87,25 @@ def main(argv=None):
     p.add_argument('--finetune', action='store_true')
     p.add_argument('--finetune_epochs', type=int, default=100)
     p.add_argument('--cycles', type=int, default=1)
+    p.add_argument('--video', default=None, help='which video of a multi-video training job (--dataset a,b,c or a multi-rank '
+                                                  '--synthetic job: synthetic<k>) to evaluate; default: the first')
     args = p.parse_args(argv)
     args.warmup = int(args.warmup * args.epochs)          # main_eval.py:106 (as main_train.parse_args): warm-up in epochs
     outf = os.path.join('result', args.outf, f'{args.suffix}')
+    # a job that fitted several videos wrote one sub-directory per video (main_train.video_outf)
+    videos = [d for d in args.dataset.split(',') if d]
+    vid_index = 0
+    if args.synthetic and args.video:
+        vid_index = int(args.video[len('synthetic'):])
+        if os.path.isdir(os.path.join(outf, args.video)):
+            outf = os.path.join(outf, args.video)
+    elif len(videos) > 1:
+        name = args.video or videos[0]
+        if name not in videos:
+            raise ValueError(f'--video {name} is not one of --dataset {videos}')
+        vid_index = videos.index(name)
+        args.dataset = name
+        outf = os.path.join(outf, name)
     PE = utils.PositionalEncoding(args.embed)
     deploy_file = os.path.join(outf, 'model_latest_deploy.pth')
     train_file = os.path.join(outf, 'model_latest.pth')
@@ -108,7 +124,7 @@ def main(argv=None):
     model = model.cuda()
     masks, originals = {}, None
     if finetune:
-        masks, originals = _prune_finetune(model, args, PE, path)
+        masks, originals = _prune_finetune(model, args, PE, path, vid_index) if vid_index else _prune_finetune(model, args, PE, path)
     if kind != 'deploy':
         for blk in model.layers:
             blk.switch_to_deploy() if blk.branch_type == 'ERB' else None
@@ -134,7 +150,7 @@ def main(argv=None):
     for s_ in args.strides:
         hw = [hw[0] * s_, hw[1] * s_]
     from .main_train import load_frames
-    frames, pos = load_frames(args, hw, 'cuda', args.dataset, 0, args.test_gap)       # val_dataset: CustomDataSet(frame_gap=test_gap)
+    frames, pos = load_frames(args, hw, 'cuda', args.dataset, vid_index, args.test_gap)       # val_dataset: CustomDataSet(frame_gap=test_gap)
     n = frames.shape[0]
     embeds = PE(pos)
     psnrs = []

@@ -2,10 +2,15 @@
 the native engine.  Same flags; the data source is a synthetic video resident in HBM (`--synthetic N`)
 or a directory of PNG frames (`../data/<dataset>` as in main_train.py:202-203, needs PIL).
 
-Differences kept deliberately small and stated here: no tensorboard/thop (not in this image); the
-checkpoint is written every `--ckpt_freq` epochs (default: every eval epoch and the last) instead of
-every epoch, because an epoch takes a fraction of a second here; per-rank videos under
-torch.distributed.run (one independent fit per GPU, RCCL only for the final gather).
+Differences kept deliberately small and stated here: no tensorboard/thop (not in this image); checkpoint
+FILES are written every `--ckpt_freq` epochs (default: every eval epoch and the last) instead of every
+epoch, because an epoch takes a fraction of a second here -- the state of the best-train-PSNR
+epoch is kept as a snapshot in HBM the moment it happens (three 30 MB device copies), so
+`model_train_best(.pth|_deploy.pth)` holds exactly the epoch the reference would have saved; per-rank
+videos under torch.distributed.run (one independent fit per GPU, RCCL only for the final gather).
+The reference's arithmetic is `--precision fp32`; the default here is fp16 (16-bit MFMA, fp32 master
+weights, dynamic loss scale), and a fit that leaves the 16-bit range falls back to the next wider
+precision from the start of the offending epoch (see `fit_video`).
 """
 import argparse
 import os
@@ -75,9 +80,14 @@ def build_parser():
     p.add_argument('--outf', default='unify')
     p.add_argument('--suffix', default='')
     # additions of this engine
-    p.add_argument('--precision', default='fp16', choices=['fp32', 'bf16', 'fp16'])
+    p.add_argument('--precision', default='fp16', choices=['fp32', 'bf16', 'fp16'],
+                   help='conv arithmetic: fp32 is the reference\'s own (main_train.py has no autocast); fp16 / bf16 run the convs '
+                        'on 16-bit MFMA with fp32 accumulation and fp32 master weights (default fp16: ~8x faster, PSNR within '
+                        '0.05 dB; falls back to bf16, then fp32, if a fit leaves its range)')
     p.add_argument('--synthetic', type=int, default=0, help='use N synthetic frames in HBM instead of ../data/<dataset>')
     p.add_argument('--ckpt_freq', type=int, default=0, help='checkpoint every K epochs (0: eval epochs and the last)')
+    p.add_argument('--dist_backend', default=None, choices=['nccl', 'gloo'],
+                   help='torch.distributed backend under a multi-process launcher (default: nccl = RCCL on GPUs)')
     return p
 
 
@@ -121,14 +131,52 @@ def load_frames(args, hw, device, name, vid_index, gap):
     return odata.load_png_dir(f'../data/{name.lower()}', args.vid, gap, device)
 
 
-def save_checkpoint(args, model, eng, epoch, best_psnr, name='model_latest.pth'):
-    """main_train.py:293-301,327 layout; ERB also writes the deploy copy (main_train.py:325-351)."""
+class Best:
+    """The reference's four best-so-far entries of a checkpoint (main_train.py:219,271-273,310-312)."""
+    def __init__(self):
+        self.train_psnr = torch.tensor(0.0)
+        self.train_msssim = torch.tensor(0.0)
+        self.val_psnr = torch.tensor(0.0)
+        self.val_msssim = torch.tensor(0.0)
+
+
+def save_checkpoint(args, model, eng, epoch, best, name='model_latest.pth', deploy_too=None):
+    """main_train.py:293-301,327 layout; ERB also writes the deploy copy (main_train.py:325-351).  `best`: a Best, or a
+    number (train PSNR; kept for callers that only track that)."""
     from . import checkpoint
+    if not isinstance(best, Best):
+        b = Best()
+        b.train_psnr = b.val_psnr = torch.as_tensor(float(best))
+        best = b
     opt = adam_state_dict(model, eng, args)
-    checkpoint.save(os.path.join(args.outf, name), model, epoch + 1, opt, best_psnr, best_psnr)
-    if args.branch_type == 'ERB':
-        checkpoint.save(os.path.join(args.outf, name.replace('.pth', '_deploy.pth')), model, epoch + 1, opt, best_psnr, best_psnr,
-                        deploy=True)
+    kw = dict(train_best_psnr=best.train_psnr, val_best_psnr=best.val_psnr, train_best_msssim=best.train_msssim,
+              val_best_msssim=best.val_msssim)
+    checkpoint.save(os.path.join(args.outf, name), model, epoch + 1, opt, **kw)
+    if args.branch_type == 'ERB' if deploy_too is None else deploy_too:
+        checkpoint.save(os.path.join(args.outf, name.replace('.pth', '_deploy.pth')), model, epoch + 1, opt, deploy=True, **kw)
+
+
+class Snapshot:
+    """Parameters + Adam moments + step count of an engine at one moment, held in HBM (three arena-sized device copies:
+    ~40 us at 720p).  Two uses: the state of the best-train-PSNR epoch until the next checkpoint write (the reference
+    writes model_train_best.pth in that epoch, main_train.py:329,348,356), and the start of the current epoch for the
+    fall-back of a fit that has left its precision's range."""
+    def __init__(self, eng, epoch):
+        self.params, self.m, self.v = eng.params.clone(), eng.adam_m.clone(), eng.adam_v.clone()
+        self.step, self.epoch = eng.global_step, epoch
+
+    def restore(self, eng):
+        eng.params.copy_(self.params); eng.adam_m.copy_(self.m); eng.adam_v.copy_(self.v)
+        eng.global_step = self.step
+
+    def write(self, args, model, eng, best, name):
+        """Write the snapshot as a checkpoint: the engine's arenas are swapped to the snapshot for the duration of the write."""
+        now = Snapshot(eng, -1)
+        self.restore(eng)
+        try:
+            save_checkpoint(args, model, eng, self.epoch, best, name)
+        finally:
+            now.restore(eng)
 
 
 def skipped_steps_warning(skipped_before: int, skipped_now: int, steps: int, precision: str, scale: float):
@@ -150,9 +198,10 @@ def adam_state_dict(model, eng, args):
     'exp_avg_sq' in model.parameters() order + one param group), so the reference's
     `optimizer.load_state_dict(checkpoint['optimizer'])` (main_eval.py:409, main_train.py:207-212) reads it."""
     state = {}
+    step = float(eng.global_step - eng.scale_state()['skipped'])      # a skipped step does not advance torch's Adam either
     for i, (k, p) in enumerate(model.named_parameters()):
         off, n = eng.layout[k]
-        state[i] = {'step': torch.tensor(float(eng.global_step)), 'exp_avg': eng.adam_m[off:off + n].view(p.shape).cpu().clone(),
+        state[i] = {'step': torch.tensor(step), 'exp_avg': eng.adam_m[off:off + n].view(p.shape).cpu().clone(),
                     'exp_avg_sq': eng.adam_v[off:off + n].view(p.shape).cpu().clone()}
     group = {'lr': args.lr, 'betas': (args.beta, 0.999), 'eps': 1e-8, 'weight_decay': 0, 'amsgrad': False, 'maximize': False,
              'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None, 'decoupled_weight_decay': False,
@@ -160,30 +209,13 @@ def adam_state_dict(model, eng, args):
     return {'state': state, 'param_groups': [group]}
 
 
-def load_adam_state(eng, model, opt):
-    """Inverse of adam_state_dict (also accepts round 1's flat {'adam_m', 'adam_v', 'step'} form)."""
-    if not opt:
-        return
-    if 'adam_m' in opt:
-        eng.adam_m.copy_(opt['adam_m'].to(eng.device)); eng.adam_v.copy_(opt['adam_v'].to(eng.device))
-        eng.global_step = int(opt.get('step', 0))
-        return
-    for i, (k, p) in enumerate(model.named_parameters()):
-        st = opt['state'].get(i)
-        if st is None:
-            continue
-        off, n = eng.layout[k]
-        eng.adam_m[off:off + n].copy_(st['exp_avg'].reshape(-1).to(eng.device))
-        eng.adam_v[off:off + n].copy_(st['exp_avg_sq'].reshape(-1).to(eng.device))
-        eng.global_step = int(float(st['step']))
-
-
-def evaluate(model, eng, args, val=None):
+def evaluate(model, eng, args, val=None, gap=None):
     """main_train.py:377-438: forward over the validation samples -- CustomDataSet(frame_gap=test_gap): sample k is entry
     k * test_gap, floor(N / test_gap) of them -- PSNR per frame, decoder FPS.  val: (frames, embeds) when the validation
     samples are not a subset of the resident training frames (frame_gap > 1)."""
     frames, embeds = val if val is not None else (eng.frames, eng.embeds)
-    idx = list(range(frames.shape[0])) if val is not None else [k * args.test_gap for k in range(frames.shape[0] // args.test_gap)]
+    gap = args.test_gap if gap is None else gap
+    idx = list(range(frames.shape[0])) if val is not None else [k * gap for k in range(frames.shape[0] // gap)]
     psnrs = []
     torch.cuda.synchronize()
     t0 = time.time()
@@ -199,22 +231,25 @@ def evaluate(model, eng, args, val=None):
 
 def train(args):
     """One independent fit per video; the videos of the job are dealt round-robin to the ranks (dist_utils.shard_videos), each
-    into its own output directory, so ranks never write the same file.  Returns the best train PSNR of this rank's last fit."""
+    into its own output directory, so ranks never write the same file.  Returns {video name: best train PSNR} of this rank."""
     rank, local, world = du.env_world()
-    torch.cuda.set_device(local)
-    dist = du.init()
+    torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+    dist = du.init(getattr(args, 'dist_backend', None))
     videos = video_list(args, world)
     mine = du.shard_videos(len(videos), world, rank)
-    best, frames_done, steps_done = 0.0, 0.0, 0.0
+    best, frames_done, steps_done = {}, 0.0, 0.0
     start = time.time()
     base_outf = args.outf
     for v in mine:
         args.outf = video_outf(base_outf, videos, v)
         b, f, st = fit_video(args, videos[v], v, rank)
-        best, frames_done, steps_done = b, frames_done + f, steps_done + st
+        best[videos[v]] = b
+        frames_done, steps_done = frames_done + f, steps_done + st
     args.outf = base_outf
     secs = time.time() - start
-    recs = du.gather_records(dist, [best, 0.0, frames_done, secs, steps_done], device=f'cuda:{local}' if dist is not None else 'cpu')
+    on_gpu = dist is not None and dist.get_backend() == 'nccl'
+    recs = du.gather_records(dist, [sum(best.values()), float(len(best)), frames_done, secs, steps_done],
+                             device=f'cuda:{torch.cuda.current_device()}' if on_gpu else 'cpu')
     if rank == 0:
         agg = du.aggregate(recs, max(r[3] for r in recs))
         print(f'Training complete in {secs:.1f}s: {agg}', flush=True)
@@ -223,7 +258,11 @@ def train(args):
     return best
 
 
-def fit_video(args, name, vid_index, rank):
+FALLBACK = {'fp16': 'bf16', 'bf16': 'fp32'}
+
+
+def fit_video(args, name, vid_index, rank, _inject=None):
+    """One fit.  _inject(epoch, eng): test hook, called after the epoch's start-of-epoch snapshot."""
     torch.manual_seed(args.manualSeed)                              # main_train.py:162
     PE = utils.PositionalEncoding(args.embed)
     args.embed_length = PE.embed_length
@@ -233,56 +272,108 @@ def fit_video(args, name, vid_index, rank):
                              sin_res=args.single_res, lower_width=args.lower_width, sigmoid=args.sigmoid,
                              deploy=args.deploy, branch_type=args.branch_type)
     total_params = sum(p.numel() for p in model.parameters()) / 1e6
-    eng = oeng.TrainEngine(model, loss_type=args.loss_type, beta=args.beta, precision=args.precision)
+    precision = args.precision
+    eng = oeng.TrainEngine(model, loss_type=args.loss_type, beta=args.beta, precision=precision)
     frames, pos = load_frames(args, eng.out_hw, eng.device, name, vid_index, args.frame_gap)
     n = frames.shape[0]
-    eng.set_video(frames, PE(pos))                                  # pos: model.py:37,68
+    embeds = PE(pos)
+    eng.set_video(frames, embeds)                                   # pos: model.py:37,68
     val = None
     if args.frame_gap != 1:                                         # the validation samples are not a subset of the training ones
         vf, vp = load_frames(args, eng.out_hw, eng.device, name, vid_index, args.test_gap)
         val = (vf, PE(vp).to(eng.device))
     os.makedirs(args.outf, exist_ok=True)
     log = open(os.path.join(args.outf, f'rank{rank}.txt'), 'a')
-    print(f'{args}\n Model Params: {total_params}M', file=log, flush=True)
+
+    def say(msg, console=True):
+        if console:
+            print(msg, flush=True)
+        print(msg, file=log, flush=True)
+    say(f'{args}\n Model Params: {total_params}M', console=False)
     g = torch.Generator()
-    best = torch.tensor(0.0)
+    best = Best()
+    best_snap, best_dirty = None, False
     start = time.time()
     steps_per_epoch = min(n, 11) if args.debug else n
     skipped_before = 0
-    for epoch in range(args.epochs):
+    epoch = 0
+    while epoch < args.epochs:
+        epoch_start = Snapshot(eng, epoch) if precision in FALLBACK else None
+        if _inject is not None:
+            _inject(epoch, eng)
         g.manual_seed(args.manualSeed + epoch)
         order = torch.randperm(n, generator=g).tolist()[:steps_per_epoch]
         entries = [(f, epoch * steps_per_epoch + i + 1, utils.lr_value(epoch % args.epochs, i, n, args)) for i, f in enumerate(order)]
         eng.set_schedule(entries)
         eng.run(len(entries))
         st = eng.stats(len(entries))                                 # syncs once per epoch
-        train_psnr = st[:, 4].mean()
-        best = torch.maximum(best, train_psnr)
-        line = (f'[{time.strftime("%Y/%m/%d %H:%M:%S")}] Rank:{rank}, Video:{name}, Epoch[{epoch + 1}/{args.epochs}], lr:{st[-1, 5]:.2e} '
-                f'PSNR: {train_psnr:.2f}, loss: {st[:, 0].mean():.5f}, {(time.time() - start) / (epoch + 1):.3f} s/epoch')
-        if epoch % max(1, args.print_freq // 10) == 0 or epoch == args.epochs - 1:
-            print(line, flush=True)
-        print(line, file=log, flush=True)
-        is_eval = (epoch + 1) % args.eval_freq == 0 or epoch > args.epochs - 10     # main_train.py:303
-        if is_eval:
-            val_psnr, fps, val_msssim = evaluate(model, eng, args, val)
-            msg = f'Eval Epoch[{epoch + 1}] PSNR {val_psnr:.2f} MS-SSIM {val_msssim:.4f} decode FPS {fps:.1f}'
-            print(msg, flush=True)
-            print(msg, file=log, flush=True)
-        if (args.ckpt_freq and (epoch + 1) % args.ckpt_freq == 0) or (not args.ckpt_freq and is_eval) or epoch == args.epochs - 1:
-            save_checkpoint(args, model, eng, epoch, best)
         sc = eng.scale_state()                                       # (the stats read above has already synchronised)
-        warn = skipped_steps_warning(skipped_before, sc['skipped'], len(entries), args.precision, sc['scale'])
+        warn = skipped_steps_warning(skipped_before, sc['skipped'], len(entries), precision, sc['scale'])
+        if warn and precision in FALLBACK:
+            # The fit has left this precision's number range: skipped steps change nothing, so it
+            # would burn the remaining epochs.  Go back to the start of this epoch and continue in the next wider
+            # precision -- same kernels built for bf16 (fp32's exponent range), then the fp32 engine; no restart.
+            wider = FALLBACK[precision]
+            say(warn.split(' Re-run')[0] + f' Restoring the start of epoch {epoch + 1} and continuing in --precision {wider}.')
+            epoch_start.restore(eng)
+            step0 = eng.global_step
+            m0, v0 = eng.adam_m.clone(), eng.adam_v.clone()
+            del eng
+            eng = oeng.TrainEngine(model, loss_type=args.loss_type, beta=args.beta, precision=wider)
+            eng.adam_m.copy_(m0); eng.adam_v.copy_(v0)
+            eng.global_step = step0
+            eng.set_video(frames, embeds)
+            precision, skipped_before = wider, 0
+            best_snap = None if best_snap is None else best_snap       # (arena-sized tensors: still valid for the new engine)
+            continue
         skipped_before = sc['skipped']
         if warn:
-            print(warn, flush=True)
-            print(warn, file=log, flush=True)
+            say(warn)
+        train_psnr = st[:, 4].mean()
+        is_train_best = bool(train_psnr > best.train_psnr)            # main_train.py:271-272
+        if is_train_best:
+            best.train_psnr = train_psnr
+            best_snap, best_dirty = Snapshot(eng, epoch), True
+        line = (f'[{time.strftime("%Y/%m/%d %H:%M:%S")}] Rank:{rank}, Video:{name}, Epoch[{epoch + 1}/{args.epochs}], lr:{st[-1, 5]:.2e} '
+                f'PSNR: {train_psnr:.2f}, best: {float(best.train_psnr):.2f}, loss: {st[:, 0].mean():.5f}, '
+                f'{(time.time() - start) / (epoch + 1):.3f} s/epoch')
+        say(line, console=epoch % max(1, args.print_freq // 10) == 0 or epoch == args.epochs - 1)
+        is_eval = (epoch + 1) % args.eval_freq == 0 or epoch > args.epochs - 10     # main_train.py:303
+        is_val_best = False
+        if is_eval:
+            val_psnr, fps, val_msssim = evaluate(model, eng, args, val)
+            is_val_best = val_psnr > float(best.val_psnr)               # main_train.py:310-312
+            if is_val_best:
+                best.val_psnr = torch.tensor(val_psnr)
+            best.val_msssim = torch.maximum(best.val_msssim, torch.tensor(val_msssim))
+            # Train MS-SSIM: the reference averages msssim_fn over the epoch's steps (main_train.py:253,258,273); it is a
+            # logging metric kept off the timed step here, so it is measured on the eval epochs, after the epoch's updates:
+            # on the training frames, which ARE the validation samples unless --frame_gap / --test_gap thin them out.
+            tr_msssim = val_msssim if (val is None and args.test_gap == 1) else evaluate(model, eng, args, None, gap=1)[2]
+            best.train_msssim = torch.maximum(best.train_msssim, torch.tensor(tr_msssim))
+            say(f'Eval best_PSNR at epoch{epoch + 1}:\tcurrent: {val_psnr:.2f}\tbest: {float(best.val_psnr):.2f} \tbest_msssim: '
+                f'{float(best.val_msssim):.4f}\t MS-SSIM {val_msssim:.4f} train MS-SSIM {tr_msssim:.4f} decode FPS {fps:.1f}')
+        write_now = (args.ckpt_freq and (epoch + 1) % args.ckpt_freq == 0) or (not args.ckpt_freq and is_eval) or epoch == args.epochs - 1
+        if is_val_best:                                                  # main_train.py:320-321: the train-mode file only
+            save_checkpoint(args, model, eng, epoch, best, 'model_val_best.pth', deploy_too=False)
+        if write_now:
+            save_checkpoint(args, model, eng, epoch, best)               # model_latest(.pth|_deploy.pth)
+            if best_dirty:                                               # model_train_best(.pth|_deploy.pth): the best EPOCH's state
+                best_snap.write(args, model, eng, best, 'model_train_best.pth')
+                best_dirty = False
+        epoch += 1
     torch.cuda.synchronize()
+    if args.branch_type == 'ERB':                                        # main_train.py:361-367
+        from . import checkpoint
+        say(f'Deploy Rep-Model Params: {checkpoint.deploy_param_count(model) / 1e6:.3f}M')
     sc = eng.scale_state()
     if sc['skipped']:
-        print(f'loss scale: {sc["skipped"]} steps skipped (non-finite gradients), scale now {sc["scale"]:g}', file=log, flush=True)
+        say(f'loss scale: {sc["skipped"]} steps skipped (non-finite gradients), scale now {sc["scale"]:g}', console=False)
+    if precision != args.precision:
+        say(f'precision: started in {args.precision}, finished in {precision}')
+    say(f'Training complete in: {time.time() - start:.1f}s', console=False)
     log.close()
-    return float(best), float(args.epochs * steps_per_epoch), float(eng.global_step)
+    return float(best.train_psnr), float(args.epochs * steps_per_epoch), float(eng.global_step)
 
 
 def main(argv=None):

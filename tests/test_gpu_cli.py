@@ -18,12 +18,29 @@ def test_train_then_eval_cli(tmp_path, monkeypatch):
     from orn_amd import checkpoint, main_eval, main_train
     monkeypatch.chdir(tmp_path)
     best = main_train.train(main_train.parse_args(FLAGS))
+    assert list(best) == ['synthetic0']
+    best = best['synthetic0']
     assert 10.0 < best < 60.0
     outf = tmp_path / 'result' / 'bunny_erb_t'
-    for f in ('model_latest.pth', 'model_latest_deploy.pth', 'rank0.txt'):
+    # N1 bookkeeping of main_train.py:293-367: latest / train-best (train + deploy) and val-best (train-mode only) files,
+    # real best-so-far entries, the "Deploy Rep-Model Params" log line
+    for f in ('model_latest.pth', 'model_latest_deploy.pth', 'model_train_best.pth', 'model_train_best_deploy.pth',
+              'model_val_best.pth', 'rank0.txt'):
         assert (outf / f).exists(), f
-    ck = torch.load(outf / 'model_latest.pth', map_location='cpu', weights_only=False)
-    assert set(ck) >= {'epoch', 'state_dict', 'train_best_psnr', 'val_best_psnr', 'optimizer'} and ck['epoch'] == 4
+    assert not (outf / 'model_val_best_deploy.pth').exists()
+    ck = torch.load(outf / 'model_latest.pth', map_location='cpu', weights_only=True)
+    assert set(ck) >= {'epoch', 'state_dict', 'train_best_psnr', 'train_best_msssim', 'val_best_psnr', 'val_best_msssim',
+                       'optimizer'} and ck['epoch'] == 4
+    assert abs(float(ck['train_best_psnr']) - best) < 1e-4
+    assert 0.0 < float(ck['train_best_msssim']) <= 1.0 and 0.0 < float(ck['val_best_msssim']) <= 1.0
+    assert float(ck['val_best_psnr']) > 10.0 and float(ck['val_best_psnr']) != float(ck['train_best_psnr'])
+    assert float(ck['optimizer']['state'][0]['step']) == 4 * 12
+    tb = torch.load(outf / 'model_train_best.pth', map_location='cpu', weights_only=True)
+    assert 1 <= tb['epoch'] <= 4 and abs(float(tb['train_best_psnr']) - best) < 1e-4
+    if tb['epoch'] != 4:                              # the best epoch's own state, not the last one's
+        assert not torch.equal(tb['state_dict']['stem.0.weight'], ck['state_dict']['stem.0.weight'])
+    log = (outf / 'rank0.txt').read_text()
+    assert 'Deploy Rep-Model Params: 3.202M' in log and 'Eval best_PSNR at epoch4' in log
     sd = checkpoint.load_state_dict_file(str(outf / 'model_latest_deploy.pth'))
     assert checkpoint.state_dict_kind(sd) == 'deploy' and len(sd) == 4 + 5 * 2 + 2
     psnr_plain = main_eval.main(FLAGS)
@@ -147,12 +164,13 @@ def test_png_directory_through_the_cli(tmp_path, monkeypatch):
     captured = {}
     orig = main_train.evaluate
 
-    def spy(model, eng, args, val=None):
-        captured['frames'], captured['embeds'] = eng.frames.clone(), eng.embeds.clone()
-        captured['val'] = None if val is None else (val[0].clone(), val[1].clone())
-        return orig(model, eng, args, val)
+    def spy(model, eng, args, val=None, gap=None):
+        if gap is None:                               # (gap=1: the train MS-SSIM pass over the training frames)
+            captured['frames'], captured['embeds'] = eng.frames.clone(), eng.embeds.clone()
+            captured['val'] = None if val is None else (val[0].clone(), val[1].clone())
+        return orig(model, eng, args, val, gap)
     monkeypatch.setattr(main_train, 'evaluate', spy)
-    best = main_train.train(main_train.parse_args(flags))
+    best = main_train.train(main_train.parse_args(flags))['tinyvid']
     assert best > 5.0
     fr = captured['frames'].cpu()
     assert fr.shape == (3, 3, 40, 60)

@@ -6,7 +6,7 @@ PSNR < 25 dB), rewinds to the snapshot taken at the start of the previous epoch 
 replays the same schedule entries on the CPU oracle (reference math, torch autograd + Adam).  Prints both per-step
 PSNR traces side by side."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # tools/ -> repo root
 sys.path.insert(0, ROOT)
 import torch
 import bench

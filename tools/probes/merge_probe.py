@@ -30,6 +30,8 @@ for (C, O, flag) in [(26, 650, 0), (26, 384, 0), (96, 384, 0)]:
     T = torch.empty(O, C, 3, 3, device=dev); wf = torch.empty(O, C, 3, 3, device=dev); bf = torch.empty(O, device=dev)
     f = lambda: _lib.check(lib.orn_erb_merge_fwd(P(w3x3), P(b[0]), P(w3x1), P(b[1]), P(w1x3), P(b[2]), P(w1), P(w2), P(w3), C, O, P(T), P(wf), P(bf), st), 'm')
     print(f'flag {flag}: C={C} O={O}: merge fwd (T + S + bias, 3 launches) {timeit(f):.1f} us')
+    if len(sys.argv) > 1 and sys.argv[1] == 'fwd':
+        continue
     g = torch.randn(O, C, 3, 3, device=dev) * 1e-6; dbf = torch.randn(O, device=dev)
     outs = [torch.empty_like(x) for x in (w3x3, b[0], w3x1, b[1], w1x3, b[2], w1, w2, w3)]
     nb = lib.orn_erb_merge_bwd_ws_bytes(C, O)

@@ -6,7 +6,7 @@ import sys
 db = sqlite3.connect(sys.argv[1])
 c = db.cursor()
 rows = list(c.execute("select name,start,end,grid_x*grid_y*grid_z/(workgroup_x*workgroup_y*workgroup_z),workgroup_x from kernels order by start"))
-idx = [i for i, r in enumerate(rows) if r[0].startswith('k_adam')]
+idx = [i for i, r in enumerate(rows) if 'k_adam' in r[0]]
 a, b = idx[-2], idx[-1]
 prev = rows[a][2]
 tot = 0
