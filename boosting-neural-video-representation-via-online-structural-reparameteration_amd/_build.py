@@ -14,6 +14,9 @@ LIB = os.path.join(HERE, 'liborn' + ('_' + TAG if TAG else '') + '.so')
 EXTRA = os.environ.get('ORN_EXTRA_DEFS', '').split() if TAG else []
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function', '-fvisibility=hidden']
+# Per-file flags.  -fno-slp-vectorize: hipcc's SLP pass packs adjacent fp32 FMAs into v_pk_fma_f32, which issues slower than
+# the two v_fma_f32 it replaces on gfx950 (the VALU-bound Fusion6 kernel: 88 -> 71 us; measured per kernel, round 3)
+FILE_FLAGS = {'orn_loss.hip': ['-fno-slp-vectorize'], 'orn_merge.hip': ['-fno-slp-vectorize']}
 
 
 def _sources():
@@ -48,7 +51,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         s, o, extra = job
         # ORN_CONV_ABLATE=1 (with force=True): timing-ablation flags of the conv kernels for tools/probes/*_ablate.py
         abl = ['-DORN_CONV_ABLATE'] if os.environ.get('ORN_CONV_ABLATE') == '1' else []
-        cmd = [HIPCC] + FLAGS + extra + abl + EXTRA + ['-c', s, '-o', o]
+        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(os.path.basename(s), []) + extra + abl + EXTRA + ['-c', s, '-o', o]
         if verbose:
             print(' '.join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

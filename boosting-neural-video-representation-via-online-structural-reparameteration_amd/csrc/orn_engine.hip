@@ -9,6 +9,7 @@
 
 struct LayerBuf {
     float *T, *wf, *bf;   // merge products (ERB) -- wf/bf alias the params for vanilla/deploy
+    float *w2t;           // tap-major copy of W2 (ERB): the T products read contiguous rows
     float *dT, *dw1p;     // merge backward scratch (ERB)
     void *mh16;           // half operand copies of the merge backward (16-bit modes, orn_merge_h16.hip)
     float *dw2t;          // dW2 tap-major [9][O][2C] (16-bit modes)
@@ -41,6 +42,7 @@ struct orn_engine {
     float gs;                        // INITIAL gradient scale of the 16-bit gradient tensors (1 for bf16, 2^20 for fp16)
     OrnScaleState *sc;               // device: the live scale + non-finite flag (dynamic loss scaling, skipped steps)
     void *merge_tables;              // device-resident grouped-GEMM problem tables (ERB)
+    OrnMergeLayer ml[ORN_MAX_LAYERS];   // (ERB) the layers as the merge launchers see them
     void *mh_tables, *mh_host;       // 16-bit modes: tables of the packed-operand merge backward (device / host)
     int merge_tiles[4];
     int ff;                          // first layer on the bf16 fast path (== n_layers: none)
@@ -134,6 +136,7 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
         const size_t wsz = (size_t)l.O * l.C * 9;
         if (d->erb) {
             L[i].T = take(wsz); L[i].wf = take(wsz); L[i].bf = take(l.O);
+            L[i].w2t = (2 * l.C * 9 * 4 * 4 <= 64 * 1024) ? take((size_t)9 * l.O * 2 * l.C) : nullptr;
             L[i].dT = take(wsz); L[i].dw1p = take((size_t)9 * 2 * l.C * l.C);
             if (d->precision != 0) {
                 L[i].mh16 = take((orn_merge_h16_layer_halfs(l.C, l.O) + 1) / 2);
@@ -243,21 +246,23 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
             e->L[i].bf = params + d->layer[i].b3x3;
         }
     else {
-        OrnMergeLayer ml[ORN_MAX_LAYERS];
+        OrnMergeLayer *ml = e->ml;
         for (int i = 0; i < d->n_layers; ++i) {
             const orn_layer_desc &l = d->layer[i];
             OrnMergeLayer &m = ml[i];
             m.C = l.C; m.O = l.O;
             m.w3x3 = params + l.w3x3; m.w3x1 = params + l.w3x1; m.w1x3 = params + l.w1x3;
             m.w1 = params + l.w1; m.w2 = params + l.w2; m.w3 = params + l.w3;
-            m.T = e->L[i].T; m.wf = e->L[i].wf;
+            m.T = e->L[i].T; m.wf = e->L[i].wf; m.w2t = e->L[i].w2t;
             m.b3x3 = params + l.b3x3; m.b1x3 = params + l.b1x3; m.b3x1 = params + l.b3x1; m.bf = e->L[i].bf;
             m.g = grads ? grads + l.w3x3 : nullptr;
             m.dT = e->L[i].dT; m.dw1p = e->L[i].dw1p;
             m.dw2 = grads ? grads + l.w2 : nullptr; m.dw3 = grads ? grads + l.w3 : nullptr;
             m.dw2t = e->L[i].dw2t;
             m.half_kind = 0; m.s2 = l.s * l.s; m.Cp = ORN_FAST_C; m.wb = m.wd = nullptr; m.biasp = nullptr;
-            if (i >= e->ff) {        // the merged kernel's 16-bit operand copies come out of the merge itself
+            // the merged kernel's 16-bit operand copies: rider work-groups of the first block's launch (forward()) when that
+            // launch exists, else the epilogue of the merge's S product
+            if (i >= e->ff && !e->stage0) {
                 m.half_kind = d->precision; m.wb = e->L[i].wb; m.wd = e->L[i].wd; m.biasp = e->L[i].biasp;
             }
         }
@@ -386,14 +391,20 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
     const OrnLinearJob lin2 = {e->h1, nullptr, 0, P + d.stem_w1, P + d.stem_b1, 1, d.stem_dim, Nout, e->pre2, e->h2};
     const float *x = e->h2;
     const int nl = d.n_layers, ff = e->ff;
+    const void *pack_t = nullptr;
+    int pack_t_blocks = 0;
     if (d.erb) {
         // online re-parameterisation of every layer (model.py:534): weights only, so all layers up front -- two grouped
         // launches (T, then S with the bias merge b3x3 + (b1x3 + b3x1) in its first tile column), each carrying one of
         // the stem's two linear layers as extra work-groups
+        // half operand copies for the merge BACKWARD (training step, 16-bit modes) as riders: the parameter-side ones behind
+        // the W2 transposes, T -> Th behind the first block's launch (or, without it, behind the S products)
+        int pk_par = 0, pk_t = 0;
+        const void *pk = (keep_z && e->mh_host) ? orn_merge_h16_pack(e->mh_host, &pk_par, &pk_t) : nullptr;
+        ORN_TRY(orn_launch_w2_transpose(nl, e->ml, st, pk, pk_par));
         ORN_TRY(orn_launch_merge_group_linear(e->merge_tables, 0, e->merge_tiles[0], lin1, st));
-        int pk_blocks = 0;
-        const void *pk = (keep_z && e->mh_host) ? orn_merge_h16_pack(e->mh_host, &pk_blocks) : nullptr;   // training step, 16-bit modes
-        ORN_TRY(orn_launch_merge_group_linear(e->merge_tables, 1, e->merge_tiles[1], lin2, st, pk, pk_blocks));
+        ORN_TRY(orn_launch_merge_group_linear(e->merge_tables, 1, e->merge_tiles[1], lin2, st, e->stage0 ? nullptr : pk, e->stage0 ? 0 : pk_t));
+        pack_t = e->stage0 ? pk : nullptr; pack_t_blocks = e->stage0 ? pk_t : 0;
     } else {
         ORN_TRY(orn_launch_linear_silu(lin1.x, lin1.row_idx, lin1.row_stride, lin1.w, lin1.bias, 1, lin1.K, lin1.N, lin1.pre, lin1.y, st));
         ORN_TRY(orn_launch_linear_silu(lin2.x, nullptr, 0, lin2.w, lin2.bias, 1, lin2.K, lin2.N, lin2.pre, lin2.y, st));
@@ -412,9 +423,18 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
         LayerBuf &b = e->L[i];
         if (i < ff) {
             if (e->prof) (void)hipEventRecord(e->prof_ev[2 * i], st);
-            if (e->stage0)   // conv + PixelShuffle + SiLU straight into layer 1's 16-bit input (b.z in the fused pair's own layout)
+            if (e->stage0) { // conv + PixelShuffle + SiLU straight into layer 1's 16-bit input (b.z in the fused pair's own layout)
+                // ERB: the 16-bit operand copies of the later blocks' merged kernels ride on this launch (orn_prep_rider.h)
+                OrnPrepLayer pl[ORN_MAX_LAYERS];
+                int np = 0;
+                if (d.erb)
+                    for (int j = ff; j < nl; ++j) {
+                        const orn_layer_desc &lj = d.layer[j];
+                        pl[np++] = OrnPrepLayer{e->L[j].wf, e->L[j].bf, lj.O, lj.C, lj.s, e->L[j].wb, e->L[j].wd, e->L[j].biasp, ORN_FAST_C};
+                    }
                 ORN_TRY(orn_launch_stage0_fwd(x, b.wf, b.bf, l.C, l.O, l.H, l.W, l.s, keep_z ? b.z : nullptr, e->L[1].xpad, ORN_FAST_C,
-                                              d.precision, st));
+                                              d.precision, st, np, pl, pack_t, pack_t_blocks));
+            }
             else
             ORN_TRY(orn_launch_conv3x3_f32(x, b.wf, b.bf, 1, l.C, l.O, l.H, l.W, l.s, 1, keep_z ? b.z : nullptr, b.a, st, nullptr));
             if (e->prof) (void)hipEventRecord(e->prof_ev[2 * i + 1], st);

@@ -22,8 +22,10 @@ int orn_launch_adam(float *p, const float *g, float *m, float *v, size_t n, doub
 // orn_stage0.hip: the fp32 block below the first 16-bit one (tiny stem image), forward / backward as one launch each
 bool orn_stage0_supported(int C, int O, int H, int W, int s);
 int orn_stage0_slabs(int O, int s);
+struct OrnPrepLayer;      // (below) 16-bit operand copies of later blocks' kernels, written by rider work-groups of this launch
 int orn_launch_stage0_fwd(const float *x, const float *wf, const float *bf, int C, int O, int H, int W, int s, float *z,
-                          void *xpad_next, int Cp, int precision, hipStream_t st);
+                          void *xpad_next, int Cp, int precision, hipStream_t st, int n_prep = 0, const OrnPrepLayer *prep = nullptr,
+                          const void *pack = nullptr, int pack_t_blocks = 0);   // pack: the merge backward's T -> Th copies as further riders
 int orn_launch_stage0_bwd(const float *x, const float *wf, const float *z, const float *dxn, int nslab, int Cp, float inv_gs, int C,
                           int O, int H, int W, int s, float *slabs, float *dx, float *dwf, float *dbf, hipStream_t st,
                           const OrnScaleState *sc = nullptr);   // sc: 1/scale from the device state instead of inv_gs
@@ -42,6 +44,7 @@ struct OrnMergeLayer {
     const float *w3x3, *w3x1, *w1x3, *w1, *w2, *w3;   // parameters
     const float *b3x3, *b1x3, *b3x1; float *bf;       // optional: bias merge folded into the S GEMM (null: separate launch)
     float *T, *wf;                                    // forward products
+    float *w2t;                                       // optional: tap-major copy of w2, [9][O][2C] (orn_launch_w2_transpose); the T products then read 16-byte rows
     const float *g;                                   // dL/dWf (in the gradient arena)
     float *dT, *dw1p, *dw2, *dw3;                     // backward scratch / outputs
     float *dw2t;                                      // 16-bit modes: dW2 tap-major [9][O][2C], interleaved by the tail kernel
@@ -51,11 +54,14 @@ struct OrnMergeLayer {
     float *biasp;
 };
 size_t orn_merge_group_bytes();
+// W2 [O][2C][3][3] -> w2t [9][O][2C] for every layer with a w2t buffer, one launch (first launch of the forward merge)
+// (pack / par_blocks: the parameter-side half copies of the merge backward's operands ride behind the transposes)
+int orn_launch_w2_transpose(int n_layers, const OrnMergeLayer *L, hipStream_t st, const void *pack = nullptr, int par_blocks = 0);
 int orn_merge_groups_build(void *dev_tables, int n_layers, const OrnMergeLayer *L, int bwd_h16);
 int orn_merge_group_tiles(int which, int n_layers, const OrnMergeLayer *L);
 int orn_launch_merge_group(const void *dev_tables, int which, int tiles, hipStream_t st);
 int orn_launch_merge_group_linear(const void *dev_tables, int which, int tiles, const OrnLinearJob &job, hipStream_t st,
-                                  const void *pack = nullptr, int pack_blocks = 0);   // pack: trailing parameter-side pack jobs (orn_merge_h16_pack)
+                                  const void *pack = nullptr, int pack_blocks = 0);   // pack: trailing T -> Th pack jobs (orn_merge_h16_pack)
 int orn_launch_merge_bias(const float *b3x3, const float *b1x3, const float *b3x1, int O, float *bf, hipStream_t st);
 int orn_launch_merge_bwd_tail(const float *g, const float *dbf, int C, int O, float *d3x3, float *db3x3, float *d3x1,
                               float *db3x1, float *d1x3, float *db1x3, const float *dw1p, float *dw1, hipStream_t st);
@@ -66,7 +72,7 @@ size_t orn_merge_h16_table_bytes();
 size_t orn_merge_h16_host_bytes();
 int orn_merge_h16_build(void *dev_tables, void *host, int n_layers, const OrnMergeLayer *L, void *const *bufs, OrnScaleState *sc);
 int orn_launch_merge_h16_bwd(const void *dev_tables, const void *host, hipStream_t st);
-const void *orn_merge_h16_pack(const void *host, int *fwd_blocks);
+const void *orn_merge_h16_pack(const void *host, int *par_blocks, int *t_blocks);
 
 // per-layer elementwise tails of the merge, all layers per launch
 struct OrnMergeMisc {

@@ -161,17 +161,20 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, int bx, int by, int bz
 //     the 4 k of two consecutive MFMA steps at once and picks its half's element (k = 2 s + (lane >> 5)) with one select;
 //   * work-group tile = (32 WM) x (32 WN): 2x2 waves for the S products, 4x1 for the T products (N = C = 96 or 26 columns).
 #define G2_KC 32
+#ifndef G2_ABL
+#define G2_ABL 0          // timing ablations of the K loop (diagnostic builds only; results WRONG): 1 no global loads, 2 no LDS stores, 4 no fragment reads, 8 no barrier
+#endif
 template <int WM, int WN>
 struct G2Regs { float4 a[WM], b[WN]; };
 
 #ifdef ORN_MERGE_STAMP
 // Diagnostic build only (tools/probes/merge_stamps.py): s_memtime phase sums of work-group (0,0,0), wave 0.
-// [0] whole kernel  [1] prologue  [2] K loop  [3] epilogue  [4] sum LDS store (incl. the wait for its global loads)
-// [5] sum global-load issue + barrier  [6] sum fragment-read issue + MFMAs  [8] chunks
-__device__ unsigned long long g_mst[16];
-extern "C" __attribute__((visibility("default"))) int orn_debug_merge_stamps(unsigned long long *out16)
+// per problem shape (slot (K / 32) % 8, 16 words): [0] whole kernel  [1] prologue  [2] K loop  [3] epilogue  [4] sum of the loop
+// iterations  [5] chunks  [6..8] M, N, K
+__device__ unsigned long long g_mst[128];
+extern "C" __attribute__((visibility("default"))) int orn_debug_merge_stamps(unsigned long long *out128)
 {
-    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_mst), sizeof(g_mst));
+    return (int)hipMemcpyFromSymbol(out128, HIP_SYMBOL(g_mst), sizeof(g_mst));
 }
 #define MST_NOW(t_) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -206,150 +209,173 @@ __device__ __forceinline__ void gemm_body2v(const GemmP &p, int bx, int by, int 
     float *C = p.C + (long)bz * p.bc;
     const int M = p.M, N = p.N, K = p.K;
     const int sam = (int)p.sam, sak = (int)p.sak, sbk = (int)p.sbk;
-    constexpr bool avec = AVEC, bvec = BVEC;       // compile-time: behind a runtime flag hipcc merges the two load forms into 4 dword loads
+    constexpr bool avec = AVEC;                    // A is contiguous in k (compile-time: the load forms differ)
+    static_assert(BVEC, "B is always loaded 16 bytes at a time");
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     // staging units: A unit u = t + 256 i -> (row u >> 3, 4 k from 4 (u & 7)); B unit u -> (k row u / BCH, 4 n from 4 (u % BCH))
-    int a_row[WM], a_ch[WM], b_kr[WN], b_ch[WN];
-    unsigned a_base[WM], b_col[WN][4];
+    // Loads go through raw buffer descriptors: a read beyond the end of a matrix returns 0 and never faults, so nothing is
+    // clamped and nothing is masked (round 3 first clamped every address and zeroed the K tail with 16 selects per unit:
+    // ~150 VALU instructions per chunk on the scalar path, three times what hides under the MFMA chain).  The K tail: B's
+    // rows k >= K lie behind its last element and read as 0; A's columns k >= K read the next row (finite weights) or 0,
+    // and fma(a, 0, acc) == acc keeps the chain exact.  Rows / columns beyond M / N only feed outputs that are never stored.
+    const unsigned a_bytes = ((unsigned)(M - 1) * (unsigned)sam + (unsigned)(K - 1) * (unsigned)sak + 1u) * 4u;
+    const unsigned b_bytes = ((unsigned)(K - 1) * (unsigned)sbk + (unsigned)N) * 4u;
+    const auto rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, a_bytes, 0x00020000);
+    const auto rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, b_bytes, 0x00020000);
+    int a_dst[WM], b_dst[WN];                              // LDS offsets inside a stage (floats)
+    unsigned a_vo[WM][avec ? 1 : 4], b_vo[WN];             // byte offsets of the unit's elements at k0 = 0
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
-        const int u = t + 256 * i;
-        a_row[i] = u >> 3; a_ch[i] = u & 7;
-        a_base[i] = (unsigned)__mul24(min(m0 + a_row[i], M - 1), sam);
+        const int u = t + 256 * i, row = u >> 3, ch = u & 7;
+#pragma unroll
+        for (int j = 0; j < (avec ? 1 : 4); ++j) a_vo[i][j] = ((unsigned)(m0 + row) * (unsigned)sam + (unsigned)(4 * ch + j) * (unsigned)sak) * 4u;
+        a_dst[i] = row * 16 + 4 * ((ch >> 1) ^ ((row >> 2) & 3)) + 2 * (ch & 1);
     }
 #pragma unroll
     for (int i = 0; i < WN; ++i) {
-        const int u = t + 256 * i;
-        b_kr[i] = u / BCH; b_ch[i] = u - b_kr[i] * BCH;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b_col[i][j] = (unsigned)min(n0 + 4 * b_ch[i] + (bvec ? 0 : j), N - (bvec ? 4 : 1));
+        const int u = t + 256 * i, kr = u / BCH, ch = u - kr * BCH;
+        b_vo[i] = ((unsigned)kr * (unsigned)sbk + (unsigned)(n0 + 4 * ch)) * 4u;
+        b_dst[i] = BM * G2_KC + kr * BN + 4 * ch;
     }
-    G2Regs<WM, WN> R;
-    // clamped loads: rows / columns beyond the edge re-read the last valid one (never stored), k beyond K the last valid k
-    // (replaced by +0.0f on its way into LDS: fma(0, 0, acc) == acc keeps the chain exact)
-    auto gload_a = [&](int i, int k0) {
-        const int k = k0 + 4 * a_ch[i];
-        if constexpr (avec) {
-            R.a[i] = *reinterpret_cast<const float4 *>(A + (a_base[i] + (unsigned)min(k, K - 4)));
+    typedef G2Regs<WM, WN> Regs;
+    // (bit_cast of the WHOLE result: indexing the builtin's vector_size result element by element, v[1], v[2] .., made hipcc 7.2
+    // load one dword and use it for every element)
+#define G2_LOAD16(rsrc_, vo_, so_) __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_, vo_, so_, 0))
+    auto gload_a = [&](Regs &R, int i, int k0) {
+        const unsigned so = (unsigned)k0 * (unsigned)sak * 4u;      // wave-uniform: the instruction's scalar offset
+        if constexpr (avec) {                                  // k contiguous: one 16-byte load (any 4-byte alignment)
+            R.a[i] = G2_LOAD16(rA, a_vo[i][0], so);
         } else {
-            R.a[i].x = A[a_base[i] + (unsigned)__mul24(min(k, K - 1), sak)];
-            R.a[i].y = A[a_base[i] + (unsigned)__mul24(min(k + 1, K - 1), sak)];
-            R.a[i].z = A[a_base[i] + (unsigned)__mul24(min(k + 2, K - 1), sak)];
-            R.a[i].w = A[a_base[i] + (unsigned)__mul24(min(k + 3, K - 1), sak)];
+            R.a[i].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, a_vo[i][0], so, 0));
+            R.a[i].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, a_vo[i][1], so, 0));
+            R.a[i].z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, a_vo[i][2], so, 0));
+            R.a[i].w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, a_vo[i][3], so, 0));
         }
     };
-    auto gload_b = [&](int i, int k0) {
-        const unsigned kb = (unsigned)__mul24(min(k0 + b_kr[i], K - 1), sbk);
-        if constexpr (bvec) {
-            R.b[i] = *reinterpret_cast<const float4 *>(B + (kb + b_col[i][0]));
-        } else {
-            R.b[i].x = B[kb + b_col[i][0]];
-            R.b[i].y = B[kb + b_col[i][1]];
-            R.b[i].z = B[kb + b_col[i][2]];
-            R.b[i].w = B[kb + b_col[i][3]];
-        }
+    auto gload_b = [&](Regs &R, int i, int k0) {
+        R.b[i] = G2_LOAD16(rB, b_vo[i], (unsigned)k0 * (unsigned)sbk * 4u);
     };
-    auto lstore_a = [&](int i, int k0, float *st) {
-        const int k = k0 + 4 * a_ch[i], row = a_row[i];
+    auto lstore_a = [&](const Regs &R, int i, int, float *st) {
         const float4 v = R.a[i];
-        float *d = st + row * 16 + 4 * ((a_ch[i] >> 1) ^ ((row >> 2) & 3)) + 2 * (a_ch[i] & 1);
-        *reinterpret_cast<float2 *>(d) = make_float2(k < K ? v.x : 0.f, k + 2 < K ? v.z : 0.f);                 // even k
-        *reinterpret_cast<float2 *>(d + BM * 16) = make_float2(k + 1 < K ? v.y : 0.f, k + 3 < K ? v.w : 0.f);   // odd k
+        float *d = st + a_dst[i];
+        *reinterpret_cast<float2 *>(d) = make_float2(v.x, v.z);                  // even k
+        *reinterpret_cast<float2 *>(d + BM * 16) = make_float2(v.y, v.w);        // odd k
     };
-    auto lstore_b = [&](int i, int k0, float *st) {
-        const bool ok = k0 + b_kr[i] < K;
-        float4 v = R.b[i];
-        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-        *reinterpret_cast<float4 *>(st + BM * G2_KC + b_kr[i] * BN + 4 * b_ch[i]) = v;
+    auto lstore_b = [&](const Regs &R, int i, int, float *st) { *reinterpret_cast<float4 *>(st + b_dst[i]) = R.b[i]; };
+    auto gload = [&](Regs &R, int k0) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) gload_a(R, i, k0);
+#pragma unroll
+        for (int i = 0; i < WN; ++i) gload_b(R, i, k0);
     };
-    auto gload = [&](int k0) {
+    auto lstore = [&](const Regs &R, int k0, float *st) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i) gload_a(i, k0);
+        for (int i = 0; i < WM; ++i) lstore_a(R, i, k0, st);
 #pragma unroll
-        for (int i = 0; i < WN; ++i) gload_b(i, k0);
+        for (int i = 0; i < WN; ++i) lstore_b(R, i, k0, st);
     };
-    auto lstore = [&](int k0, float *st) {
-#pragma unroll
-        for (int i = 0; i < WM; ++i) lstore_a(i, k0, st);
-#pragma unroll
-        for (int i = 0; i < WN; ++i) lstore_b(i, k0, st);
-    };
-    // Software pipeline over the K chunks, three LDS stages (chunk c lives in stage c % 3), two fragment register sets:
-    //   iteration i:  fragment reads of chunk i+1 -> the other set | 16 MFMAs of chunk i from this set, and BETWEEN them
-    //                 (a wave is in-order: what is written behind the chain starts when the chain has issued) chunk i+2
-    //                 -> LDS, then the global loads of chunk i+3 | barrier
-    // so the LDS round trip of chunk i+1 and the staging traffic of the later chunks sit under the MFMA chain of chunk i
-    // (a wave has no partner on its SIMD in these launches: ~1.2 waves per SIMD chip-wide).  What the barrier at the end of
-    // iteration i orders: chunk i+2 visible to the reads of iteration i+1; the reads of chunk i (finished before its MFMAs)
-    // before chunk i+3 overwrites their stage in iteration i+1.  The chunk count is rounded up to even (a chunk behind K is
-    // all zeros), so the unrolled pair has no exit in the middle.
+    // Software pipeline over the K chunks.  Everything rotates modulo 3 -- chunk c is loaded into staging register set c % 3,
+    // stored into LDS stage c % 3, and its MFMA fragments are read into fragment set c % 3 -- and the loop is unrolled by
+    // three, so every name is static:
+    //   iteration i:  16 MFMAs of chunk i, and BETWEEN them (a wave is in-order: what is written behind the chain starts
+    //                 when the chain has issued) the fragment reads of chunk i+1, the global loads of chunk i+4, then
+    //                 chunk i+2 -> LDS | barrier
+    // A chunk's loads have two iterations (~2500 cycles) to land before they are stored: inside a training step these
+    // operands come from the MALL or HBM (the launch follows 200 MB of Adam traffic), 600-2000 cycles away; with one
+    // iteration the chain of the first block (K = 650, 21 chunks) waited on them every chunk.  The LDS round trip of chunk
+    // i+1 and all staging traffic sit under the MFMA chain of chunk i (a wave has no partner on its SIMD in these launches:
+    // ~1.2 waves per SIMD chip-wide).  What the barrier at the end of iteration i orders: chunk i+2 visible to the reads of
+    // iteration i+1; the reads of chunk i (finished before its MFMAs) before chunk i+3 overwrites their stage in iteration
+    // i+1.  The chunk count is rounded up to a multiple of three (a chunk behind K is all zeros: fma(0, 0, acc) == acc).
     struct Frag { float4 a4[G2_KC / 8]; float b[G2_KC / 2]; };
     const int arow = wm * 32 + l31;
     const int a_rd = hh * (BM * 16) + arow * 16, a_sw = (arow >> 2) & 3;
-    auto fread = [&](Frag &F, const float *st) {
-        const float *ap = st + a_rd;
-        const float *bp = st + BM * G2_KC + hh * BN + wn * 32 + l31;
+    const int b_rd = BM * G2_KC + hh * BN + wn * 32 + l31;
+    // six pieces of two LDS instructions each: 0, 1 = the A fragments (two ds_read_b128), 2..5 = four B values (two ds_read2st64_b32)
+    auto fread_piece = [&](Frag &F, const float *st, int pc) {
+        if (pc < 2) {
 #pragma unroll
-        for (int j = 0; j < G2_KC / 8; ++j) F.a4[j] = *reinterpret_cast<const float4 *>(ap + 4 * (j ^ a_sw));
+            for (int j = 0; j < 2; ++j) F.a4[2 * pc + j] = *reinterpret_cast<const float4 *>(st + a_rd + 4 * ((2 * pc + j) ^ a_sw));
+        } else {
 #pragma unroll
-        for (int s2 = 0; s2 < G2_KC / 2; ++s2) F.b[s2] = bp[(2 * s2) * BN];
+            for (int j = 0; j < 4; ++j) F.b[4 * (pc - 2) + j] = st[b_rd + (2 * (4 * (pc - 2) + j)) * BN];
+        }
     };
-    const int nreal = (K + G2_KC - 1) / G2_KC, nch = (nreal + 1) & ~1;
-    Frag FX, FY;
+    auto fread = [&](Frag &F, const float *st) {
+#pragma unroll
+        for (int pc = 0; pc < 6; ++pc) fread_piece(F, st, pc);
+    };
+    const int nreal = (K + G2_KC - 1) / G2_KC, nch = (nreal + 2) / 3 * 3;
+    Frag F0, F1, F2;
+    Regs R0, R1, R2;
+    // the combine epilogue's branch terms (3 loads per output row, cold inside a training step) are requested before the K
+    // loop: 16 registers held across it instead of a ~2 us round trip behind it
+    const int gn = n0 + wn * 32 + l31, gnc = min(gn, N - 1);
+    const int ec = gnc / 9, eij = gnc - ec * 9, eii = eij / 3, ejj = eij - eii * 3;
+    float base[16];
+    if (p.epi == 1) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int gm = min(m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh, p.M - 1);
+            const long oc = (long)gm * p.Cch + ec;
+            const float p13 = (eii == 1) ? p.w1x3[oc * 3 + ejj] : 0.f;
+            const float p31 = (ejj == 1) ? p.w3x1[oc * 3 + eii] : 0.f;
+            base[reg] = p.w3x3[(long)gm * p.N + gnc] + (p13 + p31);         // association of model.py:475,495
+        }
+    }
     unsigned long long t0 = 0, t1 = 0, t2 = 0, ta = 0, tb = 0, s6 = 0;
     (void)t0; (void)t1; (void)t2; (void)ta; (void)tb; (void)s6;
     MST_NOW(t0);
-    gload(0);
+    gload(R0, 0);
+    gload(R1, G2_KC);
+    gload(R2, 2 * G2_KC);
     __syncthreads();                                       // the LDS block may still be in use by a previous role of this array
-    lstore(0, lds);
-    gload(G2_KC);
+    lstore(R0, 0, lds);
+    lstore(R1, G2_KC, lds + STAGE);                        // chunk 1 (zeros if it lies behind K)
+    gload(R0, 3 * G2_KC);
     __syncthreads();
-    fread(FX, lds);                                        // chunk 0
-    lstore(G2_KC, lds + STAGE);                            // chunk 1 (zeros if it lies behind K)
-    gload(2 * G2_KC);
-    __syncthreads();
+    fread(F0, lds);                                        // chunk 0
     MST_NOW(t1);
-    int sB = 1, sC = 2;                                    // stages of chunks i+1, i+2
-    constexpr int NPC = WM + WN;                           // staging pieces per chunk: stores ride MFMA pairs 0..3, loads pairs 4..7
-    auto step = [&](Frag &Fcur, Frag &Fnext, int i) {
+    constexpr int NPC = WM + WN;                           // staging pieces per chunk (one 16-byte unit each)
+    static_assert(2 * NPC + 6 <= G2_KC / 2, "more staging pieces than MFMA slots");
+    // Fcur: chunk i; Fnext <- chunk i+1 from stage sr; Rnew <- chunk i+4; Rold (chunk i+2) -> stage sw
+    auto step = [&](Frag &Fcur, Frag &Fnext, Regs &Rold, Regs &Rnew, const float *sr, float *sw, int i) {
         MST_NOW(ta);
         // No conditions on the chunk index in here: the step is ONE basic block (behind per-piece branches hipcc's wait
         // insertion put vmcnt(0) in front of every load, i.e. one L2 round trip per load).  Chunks behind K are read with
         // clamped addresses and stored as zeros into stages nobody reads any more; the reads behind the last chunk are unused.
-        fread(Fnext, lds + sB * STAGE);
-        __builtin_amdgcn_sched_barrier(0);                 // (the scheduler otherwise sinks these reads behind the MFMAs that should cover them)
-        float *dst = lds + sC * STAGE;
-        const int k_st = (i + 2) * G2_KC, k_ld = (i + 3) * G2_KC;
-        g2_sfor<0, G2_KC / 4>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Fcur.a4[q >> 1][2 * (q & 1)], Fcur.b[2 * q], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Fcur.a4[q >> 1][2 * (q & 1) + 1], Fcur.b[2 * q + 1], acc, 0, 0, 0);
-            g2_sfor<0, NPC>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                if constexpr (q < 4 && j * 4 / NPC == q) {
-                    if constexpr (j < WM) lstore_a(j, k_st, dst); else lstore_b(j - WM, k_st, dst);
-                }
-                if constexpr (q >= 4 && 4 + j * 4 / NPC == q) {
-                    if constexpr (j < WM) gload_a(j, k_ld); else gload_b(j - WM, k_ld);
-                }
-            });
-            __builtin_amdgcn_sched_barrier(0);             // pins the interleave: two MFMAs, then this pair's staging piece(s)
+        const int k_st = (i + 2) * G2_KC, k_ld = (i + 4) * G2_KC;
+        // one slot behind each of the 16 MFMAs (what fits under a 64-cycle MFMA without delaying the next one is ~10 simple
+        // instructions; a pair's worth of staging in ONE gap cost 340 cycles per chunk): slots 0 .. NPC-1 the global loads,
+        // then six slots of two fragment reads, then the LDS stores
+        g2_sfor<0, G2_KC / 2>([&](auto sc) {
+            constexpr int sl = decltype(sc)::value;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Fcur.a4[sl >> 2][sl & 3], Fcur.b[sl], acc, 0, 0, 0);
+            if constexpr (sl < NPC && !(G2_ABL & 1)) {
+                if constexpr (sl < WM) gload_a(Rnew, sl, k_ld); else gload_b(Rnew, sl - WM, k_ld);
+            } else if constexpr (sl >= NPC && sl < NPC + 6 && !(G2_ABL & 4)) {
+                fread_piece(Fnext, sr, sl - NPC);
+            } else if constexpr (sl >= NPC + 6 && sl < 2 * NPC + 6 && !(G2_ABL & 2)) {
+                constexpr int j = sl - NPC - 6;
+                if constexpr (j < WM) lstore_a(Rold, j, k_st, sw); else lstore_b(Rold, j - WM, k_st, sw);
+            }
+            __builtin_amdgcn_sched_barrier(0);             // pins the interleave: one MFMA, then its slot's piece
         });
-        __syncthreads();
+        if constexpr (!(G2_ABL & 8)) __syncthreads();
         MST_NOW(tb);
 #ifdef ORN_MERGE_STAMP
         s6 += tb - ta;
 #endif
-        const int tmp = sB; sB = sC; sC = (tmp + 2) % 3;   // stages rotate: (i+1, i+2) -> (i+2, i+3)
     };
-    for (int i = 0; i < nch; i += 2) {
-        step(FX, FY, i);
-        step(FY, FX, i + 1);
+    float *S0 = lds, *S1 = lds + STAGE, *S2 = lds + 2 * STAGE;
+    for (int i = 0; i < nch; i += 3) {
+        step(F0, F1, R2, R1, S1, S2, i);                   // chunk i+4 -> R1 (its chunk i+1 went to LDS an iteration ago), chunk i+2 (R2) -> S2
+        step(F1, F2, R0, R2, S2, S0, i + 1);               // chunk i+5 -> R2, chunk i+3 (R0) -> S0
+        step(F2, F0, R1, R0, S0, S1, i + 2);               // chunk i+6 -> R0, chunk i+4 (R1) -> S1
     }
     MST_NOW(t2);
-    const int gn = n0 + wn * 32 + l31;
     if (p.epi == 1 && p.bf && bx == 0 && wn == 0 && l31 == 0) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -363,19 +389,7 @@ __device__ __forceinline__ void gemm_body2v(const GemmP &p, int bx, int by, int 
     }
     if (gn < p.N) {
     if (p.epi == 1) {
-        // the branch terms of all 16 rows first (48 independent loads in flight), then the stores: interleaved per row, every
-        // row's loads wait behind the previous row's stores (they may alias as far as the compiler knows) -- 16 dependent
-        // global round trips, ~4 us of a tile's ~15
-        const int c = gn / 9, ij = gn - c * 9, ii = ij / 3, jj = ij - ii * 3;
-        float base[16];
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int gm = min(m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh, p.M - 1);
-            const long oc = (long)gm * p.Cch + c;
-            const float p13 = (ii == 1) ? p.w1x3[oc * 3 + jj] : 0.f;
-            const float p31 = (jj == 1) ? p.w3x1[oc * 3 + ii] : 0.f;
-            base[reg] = p.w3x3[(long)gm * p.N + gn] + (p13 + p31);          // association of model.py:475,495
-        }
+        const int c = ec, ij = eij;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int gm = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
@@ -410,18 +424,21 @@ __device__ __forceinline__ void gemm_body2v(const GemmP &p, int bx, int by, int 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         MST_NOW(t3);
         if (bx == 0 && by == 0 && bz == 0 && t == 0) {
-            g_mst[0] = t3 - t0; g_mst[1] = t1 - t0; g_mst[2] = t2 - t1; g_mst[3] = t3 - t2;
-            g_mst[4] = 0; g_mst[5] = 0; g_mst[6] = s6; g_mst[7] = 0; g_mst[8] = nch;
+            // one record per problem shape: slot = (K / 32) % 8, 16 words each (a grouped launch runs several problems)
+            unsigned long long *rec = g_mst + 16 * ((K / 32) & 7);
+            rec[0] = t3 - t0; rec[1] = t1 - t0; rec[2] = t2 - t1; rec[3] = t3 - t2; rec[4] = s6; rec[5] = nch; rec[6] = M; rec[7] = N; rec[8] = K;
         }
     }
 #endif
 }
 #define G2_LDS_FLOATS (3 * (128 * G2_KC + G2_KC * 32))      // three stages of the larger of the two tile shapes (4x1): 60 KB
+#define G2_LDS_BYTES(shape_) ((shape_) == 1 ? 3 * (128 * G2_KC + G2_KC * 32) * 4 : 3 * (64 * G2_KC + G2_KC * 64) * 4)   // 60 KB / 48 KB
+#define G2_LIN_ROUNDS 4                                     // output neurons per wave of a stem-layer rider work-group
 template <int WM, int WN>
 __device__ __forceinline__ void gemm_body2(const GemmP &p, int bx, int by, int bz, float *lds)
 {
-    if (p.a_vec) { if (p.b_vec) gemm_body2v<WM, WN, true, true>(p, bx, by, bz, lds); else gemm_body2v<WM, WN, true, false>(p, bx, by, bz, lds); }
-    else         { if (p.b_vec) gemm_body2v<WM, WN, false, true>(p, bx, by, bz, lds); else gemm_body2v<WM, WN, false, false>(p, bx, by, bz, lds); }
+    if (p.a_vec) gemm_body2v<WM, WN, true, true>(p, bx, by, bz, lds);
+    else gemm_body2v<WM, WN, false, true>(p, bx, by, bz, lds);
 }
 
 // Same tiling on v_mfma_f32_32x32x16_f16 (fp32 accumulate): operands are rounded to IEEE half while they are
@@ -528,23 +545,28 @@ __global__ void __launch_bounds__(256) k_gemm_f32_grouped(const GemmGroup *__res
 // The same launch with one of the stem's linear layers riding along as trailing work-groups (4 output neurons each): the
 // stem and the merge are independent latency-bound chains at the head of the step, and a graph node costs ~5 us by itself.
 __global__ void __launch_bounds__(256) k_gemm_f32_grouped_linear(const GemmGroup *__restrict__ g, OrnLinearJob job, int gemm_tiles, int lin_blocks,
-                                                                 MhPackAll pack)
+                                                                 MhPackAll pack, int tile_off)
 {
-    __shared__ __attribute__((aligned(16))) float lds[G2_LDS_FLOATS];      // one array for every role of the launch
+    // one dynamic array for every role of the launch, sized for the launch's tile shape: the static 60 KB of the larger
+    // shape held the S launch to two work-groups per CU, and its ~2,400 short rider work-groups queued behind the 320 GEMM
+    // tiles for the remaining slots -- 19 us beyond the tiles' own 23
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     // the GEMM tiles are the long latency chains: they are dispatched first (largest K first), the short work-groups behind
     // them: the stem's linear layer, then (16-bit engine modes, S launch) the parameter-side half copies of the merge
     // BACKWARD's operands
     if ((int)blockIdx.x >= gemm_tiles + lin_blocks) {
         int layer, pjob;
-        const int blk = mh_pack_decode(pack, true, (int)blockIdx.x - gemm_tiles - lin_blocks, layer, pjob);
+        const int blk = mh_pack_decode(pack, MH_TAB_T, (int)blockIdx.x - gemm_tiles - lin_blocks, layer, pjob);
         mh_pack_block(pack, layer, pjob, blk, reinterpret_cast<float (*)[65]>(lds));
         return;
     }
     if ((int)blockIdx.x >= gemm_tiles) {
-        orn_linear_silu_wave(job, (blockIdx.x - gemm_tiles) * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+#pragma unroll 1
+        for (int r = 0; r < G2_LIN_ROUNDS; ++r)
+            orn_linear_silu_wave(job, ((blockIdx.x - gemm_tiles) * G2_LIN_ROUNDS + r) * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
         return;
     }
-    const int bid = blockIdx.x;
+    const int bid = blockIdx.x + tile_off;            // (tile_off != 0: probe only, a launch of part of the tiles)
     int pi = 0;
     while (pi + 1 < g->n && bid >= g->tile_start[pi + 1]) ++pi;
     const GemmP p = g->prob[pi];
@@ -564,8 +586,8 @@ static void finish_gemm(GemmP &p)
 {
     p.a_kfast = (labs(p.sak) <= labs(p.sam)) ? 1 : 0;
     p.b_nfast = (labs(p.sbn) <= labs(p.sbk)) ? 1 : 0;
-    p.a_vec = (p.sak == 1 && p.sam % 4 == 0 && p.K % 4 == 0 && p.K >= 4 && p.ba % 4 == 0 && (uintptr_t)p.A % 16 == 0) ? 1 : 0;
-    p.b_vec = (p.sbn == 1 && p.sbk % 4 == 0 && p.N % 4 == 0 && p.N >= 4 && p.bb % 4 == 0 && (uintptr_t)p.B % 16 == 0) ? 1 : 0;
+    p.a_vec = p.sak == 1 ? 1 : 0;          // gemm_body2: A rows contiguous in k -> 16-byte buffer loads (4-byte alignment is enough)
+    p.b_vec = p.sbn == 1 ? 1 : 0;
 }
 
 static int launch_gemm(GemmP p, int batch, hipStream_t st, const char *name)
@@ -595,6 +617,15 @@ static GemmP prob_T(const float *w1, const float *w2, int C, int O, float *T)
     p.M = O; p.N = C; p.K = K2;
     p.sam = (long)K2 * 9; p.sak = 9; p.sbk = C; p.sbn = 1; p.scm = (long)C * 9; p.scn = 9;
     p.ba = 1; p.bb = 0; p.bc = 1; p.epi = 0;
+    return p;
+}
+// same product from the tap-major copy w2t [9][O][2C]: A rows are contiguous in k (16-byte loads) instead of a gather with a
+// stride of 9 floats (64 cache lines per wave-instruction: the T launch was bound by the address path, 31 us)
+static GemmP prob_T_tapmajor(const float *w1, const float *w2t, int C, int O, float *T)
+{
+    const int K2 = 2 * C;
+    GemmP p = prob_T(w1, w2t, C, O, T);
+    p.sam = K2; p.sak = 1; p.ba = (long)O * K2;
     return p;
 }
 // Wf[o,e] = (W3x3 + (P13 + P31))[o,e] + sum_m W3[o,m] * T[m,e]
@@ -744,6 +775,84 @@ extern "C" int orn_erb_merge_bwd(const float *g, const float *dbf, const float *
 }
 
 // ------------------------------------------------------------------------------------------------
+// W2 [O][2C][9] -> w2t [9][O][2C], all layers in one launch: R rows per work-group through LDS (coalesced reads along a row's
+// (k, tap) run, coalesced writes along k).
+// ------------------------------------------------------------------------------------------------
+#define W2T_ROWS 4
+struct W2TAll { int n; int blk_start[ORN_MAX_LAYERS + 1]; struct { const float *w2; float *w2t; int O, K2; } l[ORN_MAX_LAYERS]; };
+
+__global__ void __launch_bounds__(256) k_w2_transpose(W2TAll a, MhPackAll pack, int tr_blocks)
+{
+    extern __shared__ float w2s[];
+    if ((int)blockIdx.x >= tr_blocks) {                    // riders: parameter-side half copies for the merge backward
+        int layer, pjob;
+        const int blk = mh_pack_decode(pack, MH_TAB_PAR, (int)blockIdx.x - tr_blocks, layer, pjob);
+        mh_pack_block(pack, layer, pjob, blk, reinterpret_cast<float (*)[65]>(w2s));
+        return;
+    }
+    int li = 0;
+    while (li + 1 < a.n && (int)blockIdx.x >= a.blk_start[li + 1]) ++li;
+    const auto &l = a.l[li];
+    const int m0 = ((int)blockIdx.x - a.blk_start[li]) * W2T_ROWS, rows = min(W2T_ROWS, l.O - m0);
+    const int E = l.K2 * 9, t = threadIdx.x;
+    const float *src = l.w2 + (size_t)m0 * E;
+    const int n = rows * E;
+    for (int i0 = t; i0 < n; i0 += 14 * 256) {            // 14 loads in flight per thread (4 rows of 2C = 192: two rounds)
+        float v[14];
+#pragma unroll
+        for (int u = 0; u < 14; ++u) v[u] = src[min(i0 + 256 * u, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 14; ++u)
+            if (i0 + 256 * u < n) w2s[i0 + 256 * u] = v[u];
+    }
+    __syncthreads();
+    // wave w takes (tap, row) pairs w, w + 4, ...: a pair is one contiguous run of K2 floats (no per-element division)
+    const int wave = t >> 6, lane = t & 63;
+    for (int pb = wave; pb < 9 * rows; pb += 3 * 4) {       // three pairs per batch: their LDS reads go out together
+        for (int k = lane; k < l.K2; k += 64) {
+            float x[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int pr = min(pb + 4 * a, 9 * rows - 1), ij = pr / rows, r = pr - ij * rows;
+                x[a] = w2s[r * E + ij + k * 9];
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int pr = pb + 4 * a;
+                if (pr < 9 * rows) {
+                    const int ij = pr / rows, r = pr - ij * rows;
+                    l.w2t[((size_t)ij * l.O + m0 + r) * l.K2 + k] = x[a];
+                }
+            }
+        }
+    }
+}
+
+int orn_launch_w2_transpose(int n_layers, const OrnMergeLayer *L, hipStream_t st, const void *pack, int par_blocks)
+{
+    W2TAll a;
+    a.n = 0;
+    a.blk_start[0] = 0;
+    size_t smem = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        if (!L[i].w2t) continue;
+        auto &l = a.l[a.n];
+        l.w2 = L[i].w2; l.w2t = L[i].w2t; l.O = L[i].O; l.K2 = 2 * L[i].C;
+        a.blk_start[a.n + 1] = a.blk_start[a.n] + orn_cdiv(l.O, W2T_ROWS);
+        const size_t b = (size_t)W2T_ROWS * l.K2 * 9 * sizeof(float);
+        if (b > smem) smem = b;
+        ++a.n;
+    }
+    MhPackAll pk = {};
+    if (pack && par_blocks > 0) { pk = *(const MhPackAll *)pack; if (smem < 64 * 65 * sizeof(float)) smem = 64 * 65 * sizeof(float); } else par_blocks = 0;
+    if (a.n == 0 && par_blocks == 0) return 0;
+    ORN_REQUIRE(smem <= 64 * 1024, "w2_transpose: 2C = %zu too wide for the LDS tile", smem / (W2T_ROWS * 9 * sizeof(float)));
+    hipLaunchKernelGGL(k_w2_transpose, dim3(a.blk_start[a.n] + par_blocks), dim3(256), smem, st, a, pk, a.blk_start[a.n]);
+    ORN_LAUNCH_CHECK("w2_transpose");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Grouped merge for the engine: all ERB layers in four GEMM launches per step.
 // ------------------------------------------------------------------------------------------------
 static void group_add(GemmGroup &g, GemmP p, int batch)
@@ -763,15 +872,38 @@ int orn_merge_groups_build(void *dev_tables, int n_layers, const OrnMergeLayer *
     ORN_REQUIRE(2 * n_layers <= GEMM_MAXP, "merge groups: too many layers");
     GemmGroup *h = new GemmGroup[4]();
     h[0].shape = 1;             // T products: N = C columns -> 128x32 tiles
+    // Dispatch order of the S products.  The launch has a few more work-groups than the chip has CUs (720p: 320), all resident
+    // at once, two per CU where they double up -- observed: the LAST ones join the FIRST ones' CUs.  Two tiles on one CU
+    // share its matrix pipes, so the one problem whose K chain is much longer than the others' (the first block, K = O = 650)
+    // must not sit at either end: it goes behind as many tiles of the others as will double up.  Speed only.
+    int s_order[ORN_MAX_LAYERS], n_ord = 0;
+    {
+        int longest = 0, total = 0;
+        for (int i = 0; i < n_layers; ++i) {
+            if (L[i].O > L[longest].O) longest = i;
+            total += orn_cdiv(L[i].C * 9, GT) * orn_cdiv(L[i].O, GT);
+        }
+        const int overflow = total > 256 ? total - 256 : 0;
+        int cum = 0;
+        bool placed = false;
+        for (int i = n_layers - 1; i >= 0; --i) {
+            if (i == longest) continue;
+            if (!placed && cum >= overflow) { s_order[n_ord++] = longest; placed = true; }
+            s_order[n_ord++] = i;
+            cum += orn_cdiv(L[i].C * 9, GT) * orn_cdiv(L[i].O, GT);
+        }
+        if (!placed) s_order[n_ord++] = longest;
+    }
+    for (int j = 0; j < n_layers; ++j) {
+        const OrnMergeLayer &l = L[s_order[j]];
+        GemmP q = prob_S(l.w3x3, l.w3x1, l.w1x3, l.w3, l.T, l.C, l.O, l.wf);
+        q.b3x3 = l.b3x3; q.b1x3 = l.b1x3; q.b3x1 = l.b3x1; q.bf = l.bf;
+        if (l.half_kind) { q.half_kind = l.half_kind; q.wb = l.wb; q.wd = l.wd; q.biasp = l.biasp; q.s2 = l.s2; q.Cn = l.O / l.s2; q.Cp = l.Cp; }
+        group_add(h[1], q, 1);
+    }
     for (int i = 0; i < n_layers; ++i) {
         const OrnMergeLayer &l = L[i];
-        group_add(h[0], prob_T(l.w1, l.w2, l.C, l.O, l.T), 9);
-        {
-            GemmP q = prob_S(l.w3x3, l.w3x1, l.w1x3, l.w3, l.T, l.C, l.O, l.wf);
-            q.b3x3 = l.b3x3; q.b1x3 = l.b1x3; q.b3x1 = l.b3x1; q.bf = l.bf;
-            if (l.half_kind) { q.half_kind = l.half_kind; q.wb = l.wb; q.wd = l.wd; q.biasp = l.biasp; q.s2 = l.s2; q.Cn = l.O / l.s2; q.Cp = l.Cp; }
-            group_add(h[1], q, 1);
-        }
+        group_add(h[0], l.w2t ? prob_T_tapmajor(l.w1, l.w2t, l.C, l.O, l.T) : prob_T(l.w1, l.w2, l.C, l.O, l.T), 9);
         // gradient operands (dWf, dT ~ 1e-6) are scaled by 2^14 when rounded to half; weights are not
         const float GS = 16384.0f;
         GemmP q;
@@ -815,13 +947,24 @@ int orn_launch_merge_group_linear(const void *dev_tables, int which, int tiles, 
                                   int pack_blocks)
 {
     const GemmGroup *g = (const GemmGroup *)dev_tables + which;
-    int lin_blocks = orn_cdiv(job.N, 4);
+    int lin_blocks = orn_cdiv(job.N, 4 * G2_LIN_ROUNDS);
+    const size_t smem = G2_LDS_BYTES(which == 0 ? 1 : 0) > 64 * 65 * 4 ? G2_LDS_BYTES(which == 0 ? 1 : 0) : 64 * 65 * 4;
     MhPackAll pk = {};
     if (pack && pack_blocks > 0) pk = *(const MhPackAll *)pack; else pack_blocks = 0;
     static const int dbg = getenv("ORN_MERGE_DBG") ? atoi(getenv("ORN_MERGE_DBG")) : 0;      // probe switch: timing only, results WRONG
     if (dbg & 1) pack_blocks = 0;
     if (dbg & 2) lin_blocks = 0;
-    hipLaunchKernelGGL(k_gemm_f32_grouped_linear, dim3(tiles + lin_blocks + pack_blocks), dim3(256), 0, st, g, job, tiles, lin_blocks, pk);
+    if (dbg & 4) {                                    // one launch per problem: their durations inside a real step (rocprofv3 timeline)
+        GemmGroup hg;
+        if (hipMemcpy(&hg, g, sizeof(hg), hipMemcpyDeviceToHost) != hipSuccess) return ORN_E_ARG;
+        for (int i = 0; i < hg.n; ++i) {
+            const int nt = hg.tile_start[i + 1] - hg.tile_start[i];
+            hipLaunchKernelGGL(k_gemm_f32_grouped_linear, dim3(nt), dim3(256), smem, st, g, job, nt, 0, pk, hg.tile_start[i]);
+        }
+        ORN_LAUNCH_CHECK("merge_group_linear(dbg)");
+        return 0;
+    }
+    hipLaunchKernelGGL(k_gemm_f32_grouped_linear, dim3(tiles + lin_blocks + pack_blocks), dim3(256), smem, st, g, job, tiles, lin_blocks, pk, 0);
     ORN_LAUNCH_CHECK("merge_group_linear");
     return 0;
 }

@@ -48,11 +48,11 @@ size_t orn_merge_h16_layer_halfs(int C, int O)
 }
 
 // ---- pack (orn_merge_pack.h): the gradient-side jobs; the parameter-side ones ride along the forward merge ---------
-__global__ void __launch_bounds__(256) k_merge_pack(MhPackAll a, int fwd)
+__global__ void __launch_bounds__(256) k_merge_pack(MhPackAll a, int fwd /* table: MH_TAB_* */)
 {
     __shared__ float tile[64][65];
     int layer, job;
-    const int blk = mh_pack_decode(a, fwd != 0, (int)blockIdx.x, layer, job);
+    const int blk = mh_pack_decode(a, fwd, (int)blockIdx.x, layer, job);
     mh_pack_block(a, layer, job, blk, tile);
 }
 
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256) k_mgemm_h16(const MhGroup *__restrict__ g
 // ---- host side -------------------------------------------------------------------------------------------------
 struct OrnMergeH16 {
     MhPackAll pack;
-    int pack_blocks_grad, pack_blocks_fwd;
+    int pack_blocks_grad, pack_blocks_par, pack_blocks_t;
     int tiles[2];                 // total 32x32 tiles of the two GEMM launches
 };
 
@@ -186,7 +186,8 @@ int orn_merge_h16_build(void *dev_tables, void *host, int n_layers, const OrnMer
     H->pack.n = n_layers;
     H->pack.sc = sc;
     H->pack.grad_start[0] = 0;
-    H->pack.fwd_start[0] = 0;
+    H->pack.par_start[0] = 0;
+    H->pack.tt_start[0] = 0;
     for (int i = 0; i < n_layers; ++i) {
         const OrnMergeLayer &l = L[i];
         const int C = l.C, O = l.O, E = 9 * C, K2 = 2 * C;
@@ -200,8 +201,9 @@ int orn_merge_h16_build(void *dev_tables, void *host, int n_layers, const OrnMer
                                    orn_cdiv(O, 64) * orn_cdiv(E, 64), orn_cdiv(O, 64) * orn_cdiv(O, 64), orn_cdiv(O, 64) * orn_cdiv(K2 * 9, 64)};
         H->pack.grad_start[2 * i + 1] = H->pack.grad_start[2 * i] + jobs[0];
         H->pack.grad_start[2 * i + 2] = H->pack.grad_start[2 * i + 1] + jobs[3];
-        const int fj[4] = {jobs[1], jobs[2], jobs[4], jobs[5]};
-        for (int j = 0; j < 4; ++j) H->pack.fwd_start[4 * i + j + 1] = H->pack.fwd_start[4 * i + j] + fj[j];
+        const int pj[3] = {jobs[2], jobs[4], jobs[5]};
+        for (int j = 0; j < 3; ++j) H->pack.par_start[3 * i + j + 1] = H->pack.par_start[3 * i + j] + pj[j];
+        H->pack.tt_start[i + 1] = H->pack.tt_start[i] + jobs[1];
         MhProb p;
         // dW3[o][m] = (1/GS) sum_e Gh[o][e] Th[m][e]
         p = MhProb{};
@@ -228,7 +230,8 @@ int orn_merge_h16_build(void *dev_tables, void *host, int n_layers, const OrnMer
         mh_add(G[1], p);
     }
     H->pack_blocks_grad = H->pack.grad_start[2 * n_layers];
-    H->pack_blocks_fwd = H->pack.fwd_start[4 * n_layers];
+    H->pack_blocks_par = H->pack.par_start[3 * n_layers];
+    H->pack_blocks_t = H->pack.tt_start[n_layers];
     H->tiles[0] = G[0].tile_start[G[0].n];
     H->tiles[1] = G[1].tile_start[G[1].n];
     hipError_t e = hipMemcpy(dev_tables, G, 2 * sizeof(MhGroup), hipMemcpyHostToDevice);
@@ -237,11 +240,12 @@ int orn_merge_h16_build(void *dev_tables, void *host, int n_layers, const OrnMer
     return 0;
 }
 
-// the forward merge's S launch carries the parameter-side pack jobs: their table and block count for orn_launch_merge_group_linear
-const void *orn_merge_h16_pack(const void *host, int *fwd_blocks)
+// the forward riders: the pack table and the block counts of its parameter-side jobs (k_merge_prep) and of T -> Th
+const void *orn_merge_h16_pack(const void *host, int *par_blocks, int *t_blocks)
 {
     const OrnMergeH16 *H = (const OrnMergeH16 *)host;
-    *fwd_blocks = H->pack_blocks_fwd;
+    *par_blocks = H->pack_blocks_par;
+    *t_blocks = H->pack_blocks_t;
     return &H->pack;
 }
 
@@ -250,7 +254,7 @@ const void *orn_merge_h16_pack(const void *host, int *fwd_blocks)
 int orn_launch_merge_h16_bwd(const void *dev_tables, const void *host, hipStream_t st)
 {
     const OrnMergeH16 *H = (const OrnMergeH16 *)host;
-    hipLaunchKernelGGL(k_merge_pack, dim3(H->pack_blocks_grad), dim3(256), 0, st, H->pack, 0);     // G -> Gh, GT
+    hipLaunchKernelGGL(k_merge_pack, dim3(H->pack_blocks_grad), dim3(256), 0, st, H->pack, (int)MH_TAB_GRAD);     // G -> Gh, GT
     ORN_LAUNCH_CHECK("merge_pack");
     const MhGroup *g = (const MhGroup *)dev_tables;
     hipLaunchKernelGGL(k_mgemm_h16, dim3(orn_cdiv(H->tiles[0], 4)), dim3(256), 0, st, g, H->tiles[0]);

@@ -12,6 +12,8 @@
 //             group's share of dx, left as per-work-group slabs that the stem's first backward kernel sums (fixed order).
 // fp32 products and accumulation throughout (same arithmetic class as the kernels it replaces; summation order differs).
 #include "orn_internal.h"
+#include "orn_prep_rider.h"
+#include "orn_merge_pack.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -41,6 +43,9 @@ struct Stage0P {
     const OrnScaleState *sc;   // optional: 1/scale from the device-side loss-scale state
     float *dwf, *dbf;    // [O][C][3][3], [O]
     float *dx_slabs;     // [gridDim.x][C][H*W]
+    int fwd_blocks;      // forward launch: work-groups of the block itself; the ones behind them are prep riders
+    OrnPrepRider rider;  // 16-bit operand copies of the later blocks' merged kernels (orn_prep_rider.h); n == 0: none
+    int prep_blocks;     // rider work-groups of `rider`; behind them: the merge backward's T -> Th copies (orn_merge_pack.h)
 };
 
 // x / d for 0 <= x < 2^16, 2 <= d < 2^16 with m = ceil(2^32 / d); d == 1 is m = 0
@@ -90,9 +95,19 @@ __device__ __forceinline__ void batch_store(const float (&v)[U], const bool (&ok
     }
 
 template <typename H16>
-__global__ void __launch_bounds__(1024) k_stage0_fwd(Stage0P p)
+__global__ void __launch_bounds__(1024) k_stage0_fwd(Stage0P p, MhPackAll pack)
 {
     extern __shared__ float sm[];
+    if ((int)blockIdx.x >= p.fwd_blocks) {            // riders: nothing in this launch depends on them
+        const int rb = (int)blockIdx.x - p.fwd_blocks;
+        if (rb < p.prep_blocks) orn_prep_rider_block<H16>(p.rider, rb, sm);
+        else {
+            int layer, pjob;
+            const int blk = mh_pack_decode(pack, MH_TAB_T, rb - p.prep_blocks, layer, pjob);
+            mh_pack_block(pack, layer, pjob, blk, reinterpret_cast<float (*)[65]>(sm));
+        }
+        return;
+    }
     const int C16 = p.C16, H = p.H, W = p.W, HW = H * W, XW = W + 2, XP = (H + 2) * XW, WN = 9 * C16 + 4;
     float *xs = sm, *ws_ = sm + C16 * XP;
     const int nt = blockDim.x, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -340,20 +355,37 @@ int orn_stage0_slabs(int O, int s) { return s * s * orn_cdiv(O / (s * s), 16); }
 
 // precision: 1 bf16, 2 IEEE half (element type of xpad_next)
 int orn_launch_stage0_fwd(const float *x, const float *wf, const float *bf, int C, int O, int H, int W, int s, float *z,
-                          void *xpad_next, int Cp, int precision, hipStream_t st)
+                          void *xpad_next, int Cp, int precision, hipStream_t st, int n_prep, const OrnPrepLayer *prep,
+                          const void *pack, int pack_t_blocks)
 {
     Stage0P p;
     ORN_TRY(fill(p, x, wf, bf, C, O, H, W, s));
+    ORN_REQUIRE(n_prep >= 0 && n_prep <= ORN_MAX_LAYERS, "stage0_fwd: bad rider count");
+    int cmax = 0;
+    p.rider.n = n_prep;
+    p.rider.blk_start[0] = 0;
+    for (int i = 0; i < n_prep; ++i) {
+        auto &l = p.rider.l[i];
+        l.wf = prep[i].wf; l.bf = prep[i].bf; l.O = prep[i].O; l.C = prep[i].C; l.Cp = prep[i].Cp > 0 ? prep[i].Cp : prep[i].C;
+        l.s2 = prep[i].s * prep[i].s; l.Cn = prep[i].O / l.s2; l.wb = prep[i].wb; l.wd = prep[i].wd; l.biasp = prep[i].biasp;
+        p.rider.blk_start[i + 1] = p.rider.blk_start[i] + orn_cdiv(l.O, ORN_PREP_ROWS);
+        if (l.C > cmax) cmax = l.C;
+    }
     ORN_REQUIRE(xpad_next && O / (s * s) <= Cp && (precision == 1 || precision == 2), "stage0_fwd: bad output arguments");
     p.z = z; p.xpad_next = xpad_next; p.Cp = Cp;
-    const size_t smem = smem_bytes(p.C16, H, W, false);
-    const dim3 grid(orn_cdiv(O, 16)), block(orn_cdiv(H * W, 16) * 64);
+    size_t smem = smem_bytes(p.C16, H, W, false);
+    if (n_prep > 0 && orn_prep_rider_lds_bytes(cmax) > smem) smem = orn_prep_rider_lds_bytes(cmax);
+    p.fwd_blocks = orn_cdiv(O, 16);
+    p.prep_blocks = p.rider.blk_start[n_prep];
+    MhPackAll pk = {};
+    if (pack && pack_t_blocks > 0) pk = *(const MhPackAll *)pack; else pack_t_blocks = 0;
+    const dim3 grid(p.fwd_blocks + p.prep_blocks + pack_t_blocks), block(orn_cdiv(H * W, 16) * 64);
     if (precision == 2) {
         ORN_TRY(set_smem(k_stage0_fwd<_Float16>, smem));
-        hipLaunchKernelGGL(k_stage0_fwd<_Float16>, grid, block, smem, st, p);
+        hipLaunchKernelGGL(k_stage0_fwd<_Float16>, grid, block, smem, st, p, pk);
     } else {
         ORN_TRY(set_smem(k_stage0_fwd<__bf16>, smem));
-        hipLaunchKernelGGL(k_stage0_fwd<__bf16>, grid, block, smem, st, p);
+        hipLaunchKernelGGL(k_stage0_fwd<__bf16>, grid, block, smem, st, p, pk);
     }
     ORN_LAUNCH_CHECK("stage0_fwd");
     return 0;

@@ -84,6 +84,18 @@ def test_merge_fwd_bit_exact(orn, golden, C, O, seed):
         assert np.array_equal(bf.cpu().numpy(), g[f'{tag}/bf'])
 
 
+@pytest.mark.parametrize('C,O,seed', [(7, 25, 31), (5, 99, 32), (33, 65, 33), (3, 130, 34)])
+def test_merge_fwd_bit_exact_odd_shapes(orn, C, O, seed):
+    """Rows of odd length: the merge GEMM's 16-byte buffer loads start at every 4-byte alignment, the K tail (K % 32 != 0,
+    K % 4 != 0) is fed by reads beyond the end of B (zeros) and ragged tiles read beyond M / N.  Bit-equal to oracle/merge_ref.c."""
+    from oracle import c_oracle
+    w = erb_inputs(C, O, seed)
+    wf_c, bf_c, T_c = c_oracle.merge_fwd(*[w[k].numpy() for k in ERB_KEYS])
+    wf, bf = orn.ops.ErbMergeFn.apply(*[cu(w[k]) for k in ERB_KEYS])
+    assert np.array_equal(wf.cpu().numpy(), wf_c)
+    assert np.array_equal(bf.cpu().numpy(), bf_c)
+
+
 @pytest.mark.parametrize('tag,C,O', [('C6_O16', 6, 16), ('C26_O52', 26, 52)])
 def test_merge_bwd_golden(orn, golden, tag, C, O):
     g = golden('merge')
