@@ -85,6 +85,9 @@ def build_parser():
                         'on 16-bit MFMA with fp32 accumulation and fp32 master weights (default fp16: ~8x faster, PSNR within '
                         '0.05 dB; falls back to bf16, then fp32, if a fit leaves its range)')
     p.add_argument('--synthetic', type=int, default=0, help='use N synthetic frames in HBM instead of ../data/<dataset>')
+    p.add_argument('--synthetic_videos', type=int, default=0,
+                   help='with --synthetic: independent synthetic videos of the job (seeds 1234 + v), dealt round-robin to the ranks '
+                        '(default: one per rank)')
     p.add_argument('--ckpt_freq', type=int, default=0, help='checkpoint every K epochs (0: eval epochs and the last)')
     p.add_argument('--dist_backend', default=None, choices=['nccl', 'gloo'],
                    help='torch.distributed backend under a multi-process launcher (default: nccl = RCCL on GPUs)')
@@ -108,7 +111,8 @@ def video_list(args, world):
     names one frame directory each (../data/<name>, main_train.py:181); with --synthetic there are max(world, 1) seeded
     synthetic videos."""
     if args.synthetic:
-        return [f'synthetic{v}' for v in range(max(world, 1))]
+        n = getattr(args, 'synthetic_videos', 0)
+        return [f'synthetic{v}' for v in range(n if n > 0 else max(world, 1))]
     return [d for d in args.dataset.split(',') if d]
 
 

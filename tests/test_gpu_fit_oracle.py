@@ -1,0 +1,95 @@
+"""Whole-fit PSNR parity against the ORACLE (north_star: "PSNR within 0.05 dB of the reference"; the reference's figure is the
+mean of the per-step PSNRs of an epoch, main_train.py:256-257,281).  A small ERB geometry with the structure of config 2 -- one
+fp32 stem block below C = 96 blocks, so the fp32 first-block kernels, the narrow 16-bit layer, the 16-bit conv / wgrad / dgrad
+kernels, the merge (forward bit-exact, backward on 16-bit MFMA), Fusion6 and Adam all run -- is fitted with the reference
+recipe (Adam(0.5, 0.999), lr 5e-4, warm-up 0.2, cosine, shuffled epochs, b = 1) three ways from the same initial state and
+the same schedule: the CPU oracle (oracle/cpu_ref.py: torch autograd over the reference's formulas), the fp32 engine and the
+fp16 engine.  Texture content (no noise floor).  Asserted per seed: |engine - oracle| <= 0.05 dB on the last epoch's train
+PSNR and on the final decode PSNR, for both engine precisions."""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+FC, STRIDES, STEM = '2_3_26', [5, 2, 2], '64_1'
+FRAMES, EPOCHS, LR = 16, 40, 5e-4
+
+
+def _schedule(n, epochs):
+    from oracle import cpu_ref
+    g = torch.Generator()
+    out = []
+    step = 0
+    for ep in range(epochs):
+        g.manual_seed(1 + ep)
+        for it, f in enumerate(torch.randperm(n, generator=g).tolist()):
+            step += 1
+            out.append((f, step, cpu_ref.adjust_lr_value(ep, it, n, LR, epochs, int(0.2 * epochs), 'cosine', [])))
+    return out
+
+
+def _decode_psnr_oracle(sd, embeds, video):
+    from oracle import cpu_ref
+    ps = []
+    with torch.no_grad():
+        for k in range(video.shape[0]):
+            out = cpu_ref.generator_forward(sd, embeds[k:k + 1], FC, STRIDES, 'ERB')[0]
+            ps.append(float(cpu_ref.psnr_fn([out], [video[k:k + 1]])))
+    return sum(ps) / len(ps)
+
+
+@pytest.mark.parametrize('seed', [0, 1])
+def test_whole_fit_psnr_matches_the_oracle(seed):
+    import orn_amd
+    from orn_amd import data, engine, model, ops
+    from oracle import cpu_ref
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    h, w = 2 * 20, 3 * 20
+    video = data.texture_video(FRAMES, h, w, seed=77 + seed, device='cpu', cutoff=6.0)
+    embeds = cpu_ref.positional_encoding(torch.tensor([k / FRAMES for k in range(FRAMES)]), 1.25, 40)
+    sched = _schedule(FRAMES, EPOCHS)
+    sd0 = cpu_ref.init_state_dict(80, STEM, FC, STRIDES, 1, 2, 96, 'ERB', seed=1 + seed)
+    # ---- oracle fit
+    sd = {k: v.clone() for k, v in sd0.items()}
+    am = {k: torch.zeros_like(v) for k, v in sd.items()}
+    av = {k: torch.zeros_like(v) for k, v in sd.items()}
+    ps = []
+    for f, step, lr in sched:
+        _, psnr, _ = cpu_ref.train_step(sd, am, av, step, lr, embeds[f:f + 1], video[f:f + 1], FC, STRIDES, 'ERB', 'Fusion6', 0.5)
+        ps.append(float(psnr))
+    rec = {'seed': seed, 'oracle': {'train_psnr_last_epoch': sum(ps[-FRAMES:]) / FRAMES, 'decode_psnr': _decode_psnr_oracle(sd, embeds, video)}}
+    # ---- engine fits from the same state
+    for prec in ('fp32', 'fp16'):
+        gen = model.Generator(embed_length=80, stem_dim_num=STEM, fc_hw_dim=FC, expansion=1, num_blocks=1, norm='none', act='swish',
+                              bias=True, reduction=2, conv_type='conv', stride_list=STRIDES, sin_res=True, lower_width=96,
+                              sigmoid=False, deploy=False, branch_type='ERB')
+        gen.load_state_dict(sd0)
+        eng = engine.TrainEngine(gen, loss_type='Fusion6', beta=0.5, precision=prec)
+        eng.set_video(video, embeds)
+        hist = []
+        for ep in range(EPOCHS):
+            eng.set_schedule(sched[ep * FRAMES:(ep + 1) * FRAMES])
+            eng.run(FRAMES)
+            hist.append(float(eng.stats(FRAMES)[:, 4].mean()))
+        dec = []
+        for k in range(FRAMES):
+            st, _ = ops.loss_stats(eng.decode(eng.embeds[k]), eng.frames[k:k + 1], 'L2', want_grad=False)
+            dec.append(float(st[4]))
+        sc = eng.scale_state()
+        rec[prec] = {'train_psnr_last_epoch': hist[-1], 'decode_psnr': sum(dec) / len(dec), 'skipped': sc['skipped']}
+        del eng
+    out = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(out):
+        with open(os.path.join(out, f'fit_vs_oracle_seed{seed}.json'), 'w') as fjs:
+            json.dump(rec, fjs)
+    o = rec['oracle']
+    assert o['train_psnr_last_epoch'] > 25.0, rec              # the fit did converge: the comparison means something
+    for prec in ('fp32', 'fp16'):
+        e = rec[prec]
+        assert e['skipped'] == 0, rec
+        assert abs(e['train_psnr_last_epoch'] - o['train_psnr_last_epoch']) <= 0.05, rec
+        assert abs(e['decode_psnr'] - o['decode_psnr']) <= 0.05, rec

@@ -120,3 +120,35 @@ def _fits(psnr_parity, rows, deltas):
         deltas.append(r16['eval_psnr'] - r32['eval_psnr'])
         assert r32['eval_psnr'] > 35.0 and r16['eval_psnr'] > 35.0, (r32['eval_psnr'], r16['eval_psnr'])
         assert r16['skipped'] == 0 and r16['scale'] == 2.0 ** 20
+
+
+def test_dead_fp16_fit_falls_back_to_a_wider_precision(orn, tmp_path, monkeypatch):
+    """A fit that leaves fp16's range (forward activations overflow, every later step is skipped, the run
+    burns its remaining epochs) is detected at the end of the epoch, taken back to the start of that epoch -- parameters, Adam
+    moments, step count -- and continued in bf16: no restart.  Forced here by blowing up one branch kernel after the epoch's
+    snapshot was taken (1e9 x: the merged kernel itself overflows IEEE half); the restore undoes the damage, so the bf16 continuation
+    trains normally."""
+    from orn_amd import main_train
+    monkeypatch.chdir(tmp_path)
+    flags = ('-e 4 --lower_width 96 --num_blocks 1 --dataset x --frame_gap 1 --embed 1.25_40 --stem_dim_num 32_1 --reduction 2 '
+             '--fc_hw_dim 2_3_26 --expansion 1 --single_res --loss Fusion6 --warmup 0.2 --lr_type cosine --strides 5 2 2 --conv_type conv '
+             '-b 1 --lr 0.0005 --norm none --act swish --outf dead --branch_type ERB --synthetic 6 --eval_freq 100 --precision fp16').split()
+    args = main_train.parse_args(flags)
+    seen = {}
+
+    def inject(epoch, eng):
+        seen.setdefault('prec', []).append(eng.precision)
+        if epoch == 1 and 'hit' not in seen:
+            seen['hit'] = True
+            off, n = eng.layout['layers.2.rbr_3x3_branch.weight']
+            eng.params[off:off + n] *= 1.0e9
+    best, frames, steps = main_train.fit_video(args, 'synthetic0', 0, 0, _inject=inject)
+    # epochs seen by the hook: 0 (fp16), 1 (fp16, poisoned), 1 again (bf16, restored), 2, 3 (bf16)
+    assert seen['prec'] == [2, 2, 1, 1, 1], seen
+    assert math.isfinite(best) and best > 5.0
+    log = (tmp_path / 'result' / 'dead' / 'rank0.txt').read_text()
+    assert 'Restoring the start of epoch 2 and continuing in --precision bf16' in log
+    assert 'precision: started in fp16, finished in bf16' in log
+    ck = torch.load(tmp_path / 'result' / 'dead' / 'model_latest.pth', map_location='cpu', weights_only=True)
+    assert all(torch.isfinite(v).all() for v in ck['state_dict'].values())
+    assert float(ck['state_dict']['layers.2.rbr_3x3_branch.weight'].abs().max()) < 10.0       # the blow-up is gone
