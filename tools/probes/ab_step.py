@@ -10,7 +10,7 @@ res = {l: [] for l in libs}
 for r in range(rounds):
     for l in libs:
         env = dict(os.environ, ORN_LIB_PATH=os.path.abspath(l))
-        out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--no-cpu-baseline', '--no-fp32', '--steps', steps, '--warmup', '66'], env=env,
+        out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--no-cpu-baseline', '--no-fp32', '--quick', '--steps', steps, '--warmup', '66'], env=env,
                              capture_output=True, text=True)
         try:
             d = json.loads(out.stdout.strip().splitlines()[-1])

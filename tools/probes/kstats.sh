@@ -2,7 +2,7 @@
 lib=$1; tag=$2
 export ORN_LIB_PATH=$(realpath $lib)
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ks_$tag
-rocprofv3 --kernel-trace --stats -d /tmp/ks_$tag -o k --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fp32 --steps 40 --warmup 12 > /tmp/ks_$tag.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/ks_$tag -o k --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fp32 --quick --steps 40 --warmup 12 > /tmp/ks_$tag.log 2>&1
 python3 - $tag <<'PY' > $GRAFT_REPO_ROOT/gpurun_out/kstats_$2.txt
 import csv, glob, sys, collections
 tag = sys.argv[1]
