@@ -63,6 +63,8 @@ _SIGS = {
     'orn_head_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
     'orn_loss_ws_bytes': (c_size_t, [c_int] * 4),
     'orn_loss_fwd_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, P, P, P, c_size_t, P]),
+    'orn_loss_target_stats_bytes': (c_size_t, [c_int] * 4),
+    'orn_loss_target_stats': (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
     'orn_msssim_ws_bytes': (c_size_t, [c_int] * 4),
     'orn_msssim': (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
     'orn_adam_step': (c_int, [P, P, P, P, c_size_t, c_double, c_double, c_double, c_double, c_int, P]),
@@ -74,6 +76,7 @@ _SIGS = {
     'orn_engine_train_steps_graph': (c_int, [P, P, P, P, P, P, c_int32, c_int32, P]),
     'orn_engine_profile_step': (c_int, [P, P, P, P, P, P, c_int32, P, P]),
     'orn_engine_set_grad_mask': (c_int, [P, P]),
+    'orn_engine_set_target_stats': (c_int, [P, P]),
     'orn_engine_fused_kernel': (c_int, [P, c_int, POINTER(c_void_p), POINTER(c_void_p)]),
     'orn_engine_scale_state': (c_int, [P, P]),
     'orn_engine_set_grad_scale': (c_int, [P, c_float, c_float]),

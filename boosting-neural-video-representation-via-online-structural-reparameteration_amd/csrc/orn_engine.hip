@@ -28,6 +28,7 @@ struct orn_engine {
     orn_engine_desc d;
     float *params, *grads, *m, *v;
     const float *gmask;              // optional 0/1 gradient mask (prune fine-tune), same layout as the arenas
+    const float *tstats;             // optional orn_loss_target_stats of the resident video (Fusion6)
     float *ws;
     // workspace carve
     float *pre1, *h1, *pre2, *h2, *dh2;
@@ -222,6 +223,7 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
     e->d = *d;
     e->params = params; e->grads = grads; e->m = adam_m; e->v = adam_v;
     e->gmask = nullptr;
+    e->tstats = nullptr;
     e->ws = (float *)ws;
     e->graph = nullptr; e->graph_exec = nullptr; e->graph_u = nullptr; e->graph_exec_u = nullptr;
     e->prof = false;
@@ -300,6 +302,20 @@ extern "C" int orn_engine_set_grad_mask(orn_engine *e, const float *mask)
     ORN_REQUIRE(e, "engine_set_grad_mask: null engine");
     ORN_REQUIRE((uintptr_t)mask % 16 == 0, "engine_set_grad_mask: mask must be 16-byte aligned");
     e->gmask = mask;
+    if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+    if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
+    if (e->graph_exec_u) { (void)hipGraphExecDestroy(e->graph_exec_u); e->graph_exec_u = nullptr; }
+    if (e->graph_u) { (void)hipGraphDestroy(e->graph_u); e->graph_u = nullptr; }
+    return 0;
+}
+
+// orn_loss_target_stats of the frame table the next steps will be given (null removes it).  Changes what a captured step
+// does, so the graph cache is dropped.
+extern "C" int orn_engine_set_target_stats(orn_engine *e, const float *stats)
+{
+    ORN_REQUIRE(e, "engine_set_target_stats: null engine");
+    ORN_REQUIRE((uintptr_t)stats % 16 == 0, "engine_set_target_stats: stats must be 16-byte aligned");
+    e->tstats = stats;
     if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
     if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
     if (e->graph_exec_u) { (void)hipGraphExecDestroy(e->graph_exec_u); e->graph_exec_u = nullptr; }
@@ -485,7 +501,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
     const int *fidx = &cur->frame;
     ORN_TRY(forward(e, embeds, fidx, true, st));
     ORN_TRY(orn_launch_loss(e->img, frames, fidx, 3 * HWo, 1, 3, e->Hout, e->Wout, d.loss_type, 1.0f, e->stats, e->dimg,
-                            e->loss_ws, st, cur, stats_out, e->sc));
+                            e->loss_ws, st, cur, stats_out, e->sc, d.loss_type == ORN_LOSS_FUSION6 ? e->tstats : nullptr));
     const int nl = d.n_layers, ff = e->ff;
     if (ff < nl)
         ORN_TRY(e->ops->head_bwd(e->L[nl - 1].zb, P + d.head_w, e->img, e->dimg, e->Cn_last, e->Hout, e->Wout, d.sigmoid,

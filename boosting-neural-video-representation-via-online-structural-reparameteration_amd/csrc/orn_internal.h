@@ -95,7 +95,8 @@ int orn_launch_conv_bwd_f32(const float *x, const float *wf, const float *z, con
 int orn_loss_init();
 int orn_launch_loss(const float *pred, const float *target, const int *frame_idx, size_t frame_stride, int B, int Ch,
                     int H, int W, int loss_type, float loss_scale, float *stats, float *dpred, float *ws,
-                    hipStream_t st, const OrnStepCur *cur = nullptr, float *ring = nullptr, OrnScaleState *sc = nullptr);
+                    hipStream_t st, const OrnStepCur *cur = nullptr, float *ring = nullptr, OrnScaleState *sc = nullptr,
+                    const float *tstats = nullptr);   // tstats: orn_loss_target_stats of the SAME frame table (Fusion6; indexed by *frame_idx)
 
 // orn_conv_bf16.hip: the 16-bit MFMA fast path (channels-last buffers, see the file header).  The file is built
 // twice (bf16 and, with -DORN_FP16, IEEE half); the engine reaches either build through this type-erased table.

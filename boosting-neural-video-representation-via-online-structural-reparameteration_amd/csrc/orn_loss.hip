@@ -26,6 +26,12 @@ struct LossP {
     float *dpred;              // may be null
     int loss_type;
     int vec4;                  // W % 4 == 0 and 16-byte aligned planes: the fused Fusion6 kernel loads float4
+    // Fusion6, optional: the TARGET's own filtered maps G*t and G*t^2 on the valid map, [frame][2][planes][Hv][Wv], computed
+    // once per video by k_fusion6<.., TC_FILL> with the arithmetic of the in-kernel form (same taps, same fmaf order: the
+    // step's results do not change by a bit).  The target never changes during a fit, and 288 GB of HBM hold 2.9 GB of
+    // them for a 132-frame 720p video: the step then filters three maps (p, p^2, pt) instead of five.
+    float *tstats;
+    size_t tstats_stride;      // floats per frame
     float g_l1, g_l2, g_ssim;  // gradient scales (already include loss_scale and 1/n)
     int tiles_w, tiles_h;
 };
@@ -46,7 +52,8 @@ struct LossP {
 #define F6_DWP 76            // 74 columns used
 #define F6_LDS_FLOATS (2 * F6_PH * F6_PWP + 5 * F6_PH * F6_DWP + 16)
 
-template <bool GRAD>
+enum { TC_NONE = 0, TC_READ = 1, TC_FILL = 2 };
+template <bool GRAD, int TC>
 __global__ void __launch_bounds__(256) k_fusion6(LossP q)
 {
     extern __shared__ __attribute__((aligned(16))) float f6s[];
@@ -60,8 +67,28 @@ __global__ void __launch_bounds__(256) k_fusion6(LossP q)
     const int tw = blockIdx.x % q.tiles_w, th = blockIdx.x / q.tiles_w;
     const int y0 = th * F6_TH, x0 = tw * F6_TW;
     const size_t HW = (size_t)q.H * q.W;
-    const float *pp = q.pred + (size_t)plane * HW;
-    const float *tp = q.target + (q.frame_idx ? (size_t)(*q.frame_idx) * q.frame_stride : 0) + (size_t)plane * HW;
+    const size_t fr = TC == TC_FILL ? (size_t)blockIdx.z : (q.frame_idx ? (size_t)(*q.frame_idx) : 0);
+    const float *tp = q.target + fr * q.frame_stride + (size_t)plane * HW;
+    const float *pp = TC == TC_FILL ? tp : q.pred + (size_t)plane * HW;       // (TC_FILL: only the target's two maps are formed)
+    float *ts_mu = nullptr, *ts_tt = nullptr;
+    if (TC != TC_NONE) {
+        ts_mu = q.tstats + fr * q.tstats_stride + (size_t)plane * q.Hv * q.Wv;
+        ts_tt = ts_mu + (size_t)q.planes * q.Hv * q.Wv;
+    }
+    // the cached target statistics of this thread's nine map positions (column filter mapping below) are requested first: two
+    // barriers lie between here and their use.  (Loaded where they are used, they cost more than the two filters they save:
+    // with two work-groups per CU nothing covers a round trip to HBM in the middle of a phase.)
+    constexpr int RPT = 9;
+    const int vrg = t / F6_DWP, vj = t - vrg * F6_DWP, vr4 = vrg == 2 ? 17 : vrg * RPT;
+    float c_mu[RPT], c_tt[RPT];
+    if (TC == TC_READ && t < 3 * F6_DWP) {
+#pragma unroll
+        for (int o = 0; o < RPT; ++o) {
+            const int vy = min(max(y0 - 10 + vr4 + o, 0), q.Hv - 1), vx = min(max(x0 - 10 + vj, 0), q.Wv - 1);
+            c_mu[o] = ts_mu[(size_t)vy * q.Wv + vx];
+            c_tt[o] = ts_tt[(size_t)vy * q.Wv + vx];
+        }
+    }
     // ---- patch rows y0-10 .. y0+25, columns x0-10 .. x0+73 (LDS column c <-> image column x0 - 10 + c); zero outside the image
     if (q.vec4) {           // rows are 16-byte aligned: float4 units from image column x0 - 12
         constexpr int NU = 22, NIT = (F6_PH * NU + 255) / 256;
@@ -116,6 +143,7 @@ __global__ void __launch_bounds__(256) k_fusion6(LossP q)
             b[4 * k] = vb.x; b[4 * k + 1] = vb.y; b[4 * k + 2] = vb.z; b[4 * k + 3] = vb.w;
         }
         float sp[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0}, spp[4] = {0, 0, 0, 0}, stt[4] = {0, 0, 0, 0}, spt[4] = {0, 0, 0, 0};
+        constexpr bool P_MAPS = TC != TC_FILL, T_MAPS = TC != TC_READ;       // which of the five maps this mode forms
 #pragma unroll
         for (int k = 0; k < 14; ++k) {
             const float aa = a[k] * a[k], bb = b[k] * b[k], ab = a[k] * b[k];
@@ -124,20 +152,21 @@ __global__ void __launch_bounds__(256) k_fusion6(LossP q)
                 const int tap = k - o;
                 if (tap >= 0 && tap < 11) {
                     const float g = c_gauss[tap];
-                    sp[o] = fmaf(g, a[k], sp[o]);
-                    st[o] = fmaf(g, b[k], st[o]);
-                    spp[o] = fmaf(g, aa, spp[o]);
-                    stt[o] = fmaf(g, bb, stt[o]);
-                    spt[o] = fmaf(g, ab, spt[o]);
+                    if (P_MAPS) { sp[o] = fmaf(g, a[k], sp[o]); spp[o] = fmaf(g, aa, spp[o]); spt[o] = fmaf(g, ab, spt[o]); }
+                    if (T_MAPS) { st[o] = fmaf(g, b[k], st[o]); stt[o] = fmaf(g, bb, stt[o]); }
                 }
             }
         }
         float *h = Hm + r * F6_DWP + c4;
-        *reinterpret_cast<float4 *>(h) = make_float4(sp[0], sp[1], sp[2], sp[3]);
-        *reinterpret_cast<float4 *>(h + F6_PH * F6_DWP) = make_float4(st[0], st[1], st[2], st[3]);
-        *reinterpret_cast<float4 *>(h + 2 * F6_PH * F6_DWP) = make_float4(spp[0], spp[1], spp[2], spp[3]);
-        *reinterpret_cast<float4 *>(h + 3 * F6_PH * F6_DWP) = make_float4(stt[0], stt[1], stt[2], stt[3]);
-        *reinterpret_cast<float4 *>(h + 4 * F6_PH * F6_DWP) = make_float4(spt[0], spt[1], spt[2], spt[3]);
+        if (P_MAPS) {
+            *reinterpret_cast<float4 *>(h) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+            *reinterpret_cast<float4 *>(h + 2 * F6_PH * F6_DWP) = make_float4(spp[0], spp[1], spp[2], spp[3]);
+            *reinterpret_cast<float4 *>(h + 4 * F6_PH * F6_DWP) = make_float4(spt[0], spt[1], spt[2], spt[3]);
+        }
+        if (T_MAPS) {
+            *reinterpret_cast<float4 *>(h + F6_PH * F6_DWP) = make_float4(st[0], st[1], st[2], st[3]);
+            *reinterpret_cast<float4 *>(h + 3 * F6_PH * F6_DWP) = make_float4(stt[0], stt[1], stt[2], stt[3]);
+        }
     }
     __syncthreads();
     // ---- column filter + SSIM map + dS maps on valid-map rows y0-10+i (i < 26), columns x0-10+j (j < 74).
@@ -145,12 +174,11 @@ __global__ void __launch_bounds__(256) k_fusion6(LossP q)
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     float ssum = 0.f;
     if (t < 3 * F6_DWP) {
-        constexpr int RPT = 9;
-        const int rg = t / F6_DWP, j = t - rg * F6_DWP;
-        const int r4 = rg == 2 ? 17 : rg * RPT;
+        const int rg = vrg, j = vj, r4 = vr4;
         float v[5][RPT];
 #pragma unroll
         for (int m = 0; m < 5; ++m) {
+            if ((TC == TC_READ && (m == 1 || m == 3)) || (TC == TC_FILL && !(m == 1 || m == 3))) continue;
             float col[RPT + 10];
 #pragma unroll
             for (int k = 0; k < RPT + 10; ++k) col[k] = Hm[(m * F6_PH + r4 + k) * F6_DWP + j];
@@ -167,21 +195,43 @@ __global__ void __launch_bounds__(256) k_fusion6(LossP q)
             const int i = r4 + o;
             const int vy = y0 - 10 + i, vx = x0 - 10 + j;
             float dm = 0.f, dq = 0.f, dr = 0.f;
+            if (TC == TC_FILL) {                        // the owned part of the two target maps, once
+                if (vy >= 0 && vy < q.Hv && vx >= 0 && vx < q.Wv && i >= 10 && j >= 10 && j < F6_TW + 10 && (rg < 2 || o > 0)) {
+                    ts_mu[(size_t)vy * q.Wv + vx] = v[1][o];
+                    ts_tt[(size_t)vy * q.Wv + vx] = v[3][o];
+                }
+                continue;
+            }
             if (vy >= 0 && vy < q.Hv && vx >= 0 && vx < q.Wv && j < F6_TW + 10) {
-                const float m = v[0][o], mu = v[1][o], qq = v[2][o], tt = v[3][o], rr = v[4][o];
+                const float m = v[0][o], qq = v[2][o], rr = v[4][o];
+                const float mu = TC == TC_READ ? c_mu[o] : v[1][o];
+                const float tt = TC == TC_READ ? c_tt[o] : v[3][o];
                 const float sp = qq - m * m, st = tt - mu * mu, spt = rr - m * mu;
                 const float A1 = 2.f * m * mu + C1, A2 = 2.f * spt + C2;
                 const float B1 = m * m + mu * mu + C1, B2 = sp + st + C2;
-                const float inv = 1.0f / (B1 * B2);
+                // two reciprocals (v_rcp_f32 + one Newton step: < 1 ulp) instead of four IEEE divisions (~10 instructions each)
+                float i1 = __builtin_amdgcn_rcpf(B1), i2 = __builtin_amdgcn_rcpf(B2);
+                i1 = i1 * (2.0f - B1 * i1);
+                i2 = i2 * (2.0f - B2 * i2);
+                const float inv = i1 * i2;
                 const float S = A1 * A2 * inv;
                 if (i >= 10 && j >= 10 && (rg < 2 || o > 0)) ssum += S;      // this tile's own part of the map, once
-                dm = 2.f * mu * (A2 - A1) * inv - 2.f * m * S / B1 + 2.f * m * S / B2;
-                dq = -S / B2;
+                dm = 2.f * mu * (A2 - A1) * inv - 2.f * m * S * i1 + 2.f * m * S * i2;
+                dq = -S * i2;
                 dr = 2.f * A1 * inv;
             }
             float *d = Dm + i * F6_DWP + j;
             d[0] = dm; d[F6_DH * F6_DWP] = dq; d[2 * F6_DH * F6_DWP] = dr;      // X is dead since the barrier above
         }
+    }
+    if (TC == TC_FILL) return;
+    // this thread's four output pixels (last phase) are requested before the two adjoint passes
+    const int fc = t & (F6_TW - 1), fr4 = (t >> 6) * 4;
+    float fp[4], ft[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const size_t oo = (size_t)min(y0 + fr4 + o, q.H - 1) * q.W + min(x0 + fc, q.W - 1);
+        fp[o] = pp[oo]; ft[o] = tp[oo];
     }
     __syncthreads();
     float sabs = 0.f, ssq = 0.f;
@@ -212,7 +262,7 @@ __global__ void __launch_bounds__(256) k_fusion6(LossP q)
     }
     // ---- adjoint column filter + L1 term: thread = (column c, 4 rows)
     {
-        const int c = t & (F6_TW - 1), r4 = (t >> 6) * 4;
+        const int c = fc, r4 = fr4;
         float am[4] = {0, 0, 0, 0}, aq[4] = {0, 0, 0, 0}, ar[4] = {0, 0, 0, 0};
         if (GRAD) {
 #pragma unroll
@@ -235,7 +285,7 @@ __global__ void __launch_bounds__(256) k_fusion6(LossP q)
             const int gy = y0 + r4 + o;
             if (gy >= q.H || gx >= q.W) continue;
             const size_t oo = (size_t)gy * q.W + gx;
-            const float p = pp[oo], tg = tp[oo], d = p - tg;
+            const float p = fp[o], tg = ft[o], d = p - tg;
             sabs += fabsf(d);
             ssq = fmaf(d, d, ssq);
             if (GRAD) {
@@ -377,8 +427,11 @@ static int ensure_fusion6_lds()
 {
     static bool done = false;
     if (done) return 0;
-    hipError_t e = hipFuncSetAttribute((const void *)k_fusion6<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F6_LDS_FLOATS * 4);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_fusion6<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F6_LDS_FLOATS * 4);
+    hipError_t e = hipSuccess;
+    const void *kerns[] = {(const void *)k_fusion6<true, TC_NONE>, (const void *)k_fusion6<false, TC_NONE>, (const void *)k_fusion6<true, TC_READ>,
+                           (const void *)k_fusion6<false, TC_READ>, (const void *)k_fusion6<false, TC_FILL>};
+    for (const void *k : kerns)
+        if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, F6_LDS_FLOATS * 4);
     if (e != hipSuccess) { orn_set_error("loss: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     done = true;
     return 0;
@@ -389,7 +442,7 @@ int orn_loss_init() { ORN_TRY(ensure_gauss()); return ensure_fusion6_lds(); }
 
 int orn_launch_loss(const float *pred, const float *target, const int *frame_idx, size_t frame_stride, int B, int Ch,
                     int H, int W, int loss_type, float loss_scale, float *stats, float *dpred, float *ws,
-                    hipStream_t st, const OrnStepCur *cur, float *ring, OrnScaleState *sc)
+                    hipStream_t st, const OrnStepCur *cur, float *ring, OrnScaleState *sc, const float *tstats)
 {
     ORN_REQUIRE(loss_type == ORN_LOSS_L2 || loss_type == ORN_LOSS_L1 || loss_type == ORN_LOSS_FUSION6,
                 "loss: unsupported loss_type %d", loss_type);
@@ -402,6 +455,7 @@ int orn_launch_loss(const float *pred, const float *target, const int *frame_idx
     q.planes = g.planes; q.H = H; q.W = W; q.Hv = g.Hv; q.Wv = g.Wv;
     q.part_ssim = ws; q.part_l1 = ws + g.off_pl;
     q.dpred = dpred; q.loss_type = loss_type;
+    q.tstats = const_cast<float *>(tstats); q.tstats_stride = 2 * g.nmap;
     q.vec4 = (W % 4 == 0 && ((uintptr_t)pred | (uintptr_t)target) % 16 == 0 && (frame_stride % 4 == 0 || !frame_idx)) ? 1 : 0;
     const double n = (double)g.planes * H * W;
     q.g_l1 = (float)((loss_type == ORN_LOSS_FUSION6 ? 0.7 : 1.0) * loss_scale / n);
@@ -413,7 +467,8 @@ int orn_launch_loss(const float *pred, const float *target, const int *frame_idx
         const dim3 gr(g.tw * g.th, g.planes), bl(256);
         const bool gd = q.dpred != nullptr;
         if (loss_type == ORN_LOSS_FUSION6) {
-            if (gd) hipLaunchKernelGGL((k_fusion6<true>), gr, bl, F6_LDS_FLOATS * 4, st, q); else hipLaunchKernelGGL((k_fusion6<false>), gr, bl, F6_LDS_FLOATS * 4, st, q);
+            if (tstats) { if (gd) hipLaunchKernelGGL((k_fusion6<true, TC_READ>), gr, bl, F6_LDS_FLOATS * 4, st, q); else hipLaunchKernelGGL((k_fusion6<false, TC_READ>), gr, bl, F6_LDS_FLOATS * 4, st, q); }
+            else if (gd) hipLaunchKernelGGL((k_fusion6<true, TC_NONE>), gr, bl, F6_LDS_FLOATS * 4, st, q); else hipLaunchKernelGGL((k_fusion6<false, TC_NONE>), gr, bl, F6_LDS_FLOATS * 4, st, q);
         }
         else if (loss_type == ORN_LOSS_L2) { if (gd) hipLaunchKernelGGL((k_loss_grad<ORN_LOSS_L2, true>), gr, bl, 0, st, q); else hipLaunchKernelGGL((k_loss_grad<ORN_LOSS_L2, false>), gr, bl, 0, st, q); }
         else { if (gd) hipLaunchKernelGGL((k_loss_grad<ORN_LOSS_L1, true>), gr, bl, 0, st, q); else hipLaunchKernelGGL((k_loss_grad<ORN_LOSS_L1, false>), gr, bl, 0, st, q); }
@@ -422,6 +477,30 @@ int orn_launch_loss(const float *pred, const float *target, const int *frame_idx
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, st, q.part_ssim, loss_type == ORN_LOSS_FUSION6 ? n_tiles : 0, q.part_l1, n_tiles, n,
                        (double)g.nmap, loss_type, loss_scale, stats, cur, ring, sc);
     ORN_LAUNCH_CHECK("loss_finalize");
+    return 0;
+}
+
+// The target side of Fusion6's SSIM statistics for `n` frames (LossP::tstats): out [n][2][Ch][H-10][W-10].
+extern "C" size_t orn_loss_target_stats_bytes(int n, int Ch, int H, int W)
+{
+    if (n <= 0 || Ch <= 0 || H <= 10 || W <= 10) return 0;
+    return (size_t)n * 2 * Ch * (H - 10) * (W - 10) * sizeof(float);
+}
+
+extern "C" int orn_loss_target_stats(const float *frames, int n, int Ch, int H, int W, float *out, void *stream)
+{
+    ORN_REQUIRE(frames && out && n > 0 && Ch > 0 && H > 10 && W > 10 && n <= 65535, "loss_target_stats: bad arguments");
+    ORN_TRY(orn_loss_init());
+    const LossGeom g = loss_geom(1, Ch, H, W);
+    LossP q = {};
+    q.pred = frames; q.target = frames; q.frame_idx = nullptr; q.frame_stride = (size_t)Ch * H * W;
+    q.planes = g.planes; q.H = H; q.W = W; q.Hv = g.Hv; q.Wv = g.Wv;
+    q.tstats = out; q.tstats_stride = 2 * g.nmap;
+    q.loss_type = ORN_LOSS_FUSION6;
+    q.vec4 = (W % 4 == 0 && (uintptr_t)frames % 16 == 0) ? 1 : 0;
+    q.tiles_w = g.tw; q.tiles_h = g.th;
+    hipLaunchKernelGGL((k_fusion6<false, TC_FILL>), dim3(g.tw * g.th, g.planes, n), dim3(256), F6_LDS_FLOATS * 4, (hipStream_t)stream, q);
+    ORN_LAUNCH_CHECK("loss_target_stats");
     return 0;
 }
 

@@ -87,7 +87,7 @@ class TrainEngine:
     """Native training engine for one video (one process / one GPU per video)."""
 
     def __init__(self, model, loss_type: str = 'Fusion6', beta: float = 0.5, precision: str = 'fp32',
-                 device: Optional[torch.device] = None, n_slots: int = 4096):
+                 device: Optional[torch.device] = None, n_slots: int = 4096, target_cache: bool = True):
         if not torch.cuda.is_available():
             raise OrnError('TrainEngine needs a GPU: there is no CPU path')
         self.device = torch.device(device or f'cuda:{torch.cuda.current_device()}')
@@ -116,6 +116,8 @@ class TrainEngine:
         check(lib().orn_engine_create(byref(self.desc), _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.adam_m),
                                       _lib.ptr(self.adam_v), _lib.ptr(self.ws), c_size_t(nbytes), byref(self._h)),
               'orn_engine_create')
+        self.target_cache = bool(target_cache) and loss_type == 'Fusion6'
+        self.tstats = None
         self.n_slots = n_slots
         self.stats_ring = torch.zeros(n_slots, 8, device=dev)
         self.cursor = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -149,6 +151,21 @@ class TrainEngine:
             raise OrnError(f'embeds {tuple(embeds.shape)} vs ({frames.shape[0]}, {self.desc.embed_len})')
         self.frames = frames.to(self.device, torch.float32).contiguous()
         self.embeds = embeds.to(self.device, torch.float32).contiguous()
+        # Fusion6: the target side of the SSIM statistics, once per video (two valid-map planes per image plane: 2.9 GB for
+        # 132 frames of 720p, 29 GB for 600 of 1080p, of 288 GB); the step then filters three maps instead of five.
+        # Skipped when it does not fit beside the video with room to spare.
+        self.tstats = None
+        check(lib().orn_engine_set_target_stats(self._h, None), 'orn_engine_set_target_stats')
+        if self.target_cache:
+            n, _, H, W = self.frames.shape
+            nbytes = lib().orn_loss_target_stats_bytes(n, 3, H, W)
+            free, _ = torch.cuda.mem_get_info(self.device)
+            if 0 < nbytes < free // 2:
+                self.tstats = torch.empty(nbytes // 4, device=self.device)
+                cur = torch.cuda.current_stream()
+                check(lib().orn_loss_target_stats(_lib.ptr(self.frames), n, 3, H, W, _lib.ptr(self.tstats), c_void_p(cur.cuda_stream)),
+                      'orn_loss_target_stats')
+                check(lib().orn_engine_set_target_stats(self._h, _lib.ptr(self.tstats)), 'orn_engine_set_target_stats')
 
     def set_schedule(self, entries: Sequence[Tuple[int, int, float]]):
         """Upload the next run's per-step (frame, global step, lr) entries and rewind the cursor."""

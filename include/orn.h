@@ -150,6 +150,13 @@ ORN_API int orn_head_bwd(const float *a, const float *w, const float *out, const
 ORN_API size_t orn_loss_ws_bytes(int B, int Ch, int H, int W);
 ORN_API int orn_loss_fwd_bwd(const float *pred, const float *target, int B, int Ch, int H, int W, int loss_type,
                      float loss_scale, float *stats, float *dpred, void *ws, size_t ws_bytes, void *stream);
+/* Fusion6, engine only: the TARGET side of the SSIM statistics (utils.py:160 -> pytorch_msssim ssim: the 11-tap Gaussian of
+ * t and of t*t on the valid map) of `n` resident frames [n][Ch][H][W] -> out [n][2][Ch][H-10][W-10] (orn_loss_target_stats_bytes).
+ * A video's frames never change during its fit, so the engine can be handed this table once (orn_engine_set_target_stats) and
+ * its steps then filter three maps (p, p*p, p*t) instead of five; same taps and fmaf order as the in-step form: results are
+ * bit-identical with and without it. */
+ORN_API size_t orn_loss_target_stats_bytes(int n, int Ch, int H, int W);
+ORN_API int orn_loss_target_stats(const float *frames, int n, int Ch, int H, int W, float *out, void *stream);
 
 /* ---- N3  msssim_fn: pytorch_msssim.ms_ssim(pred, target, data_range=1, size_average=True)   utils.py:201-211
  * Logging metric of the reference's train/eval loops (main_train.py:254); synchronises the stream (not for the
@@ -216,6 +223,9 @@ ORN_API int orn_engine_train_step(orn_engine *e, const float *frames, const floa
  * multiplied by it before Adam.  The prune fine-tune of main_eval.py:213-531 -- torch.nn.utils.prune keeps
  * weight = weight_orig * mask, so pruned entries never receive a gradient -- and its frozen tensors. */
 ORN_API int orn_engine_set_grad_mask(orn_engine *e, const float *mask);
+/* Optional table of orn_loss_target_stats for the frame table the following steps are given (device, 16-byte aligned, caller-owned,
+ * alive while set; null removes it).  Fusion6 only; other loss types ignore it. */
+ORN_API int orn_engine_set_target_stats(orn_engine *e, const float *stats);
 /* One eager training step with HIP events around the conv launches, on the launch stream; synchronises it.  ms_out (host,
  * 2*n_layers + 2 floats): [i] forward conv of layer i, [n_layers + i] dgrad launch of layer i (0: none), [2*n_layers] the
  * batched wgrad launch of the 16-bit layers, [2*n_layers + 1] its split-K reduction (0 in fp32 mode, where each layer's

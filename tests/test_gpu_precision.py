@@ -152,3 +152,27 @@ def test_dead_fp16_fit_falls_back_to_a_wider_precision(orn, tmp_path, monkeypatc
     ck = torch.load(tmp_path / 'result' / 'dead' / 'model_latest.pth', map_location='cpu', weights_only=True)
     assert all(torch.isfinite(v).all() for v in ck['state_dict'].values())
     assert float(ck['state_dict']['layers.2.rbr_3x3_branch.weight'].abs().max()) < 10.0       # the blow-up is gone
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'fp16'])
+def test_target_statistics_cache_changes_nothing(orn, prec):
+    """Fusion6's target-side SSIM statistics (G*t, G*t^2) read from the per-video table (orn_loss_target_stats) instead of being
+    filtered in every step: same taps, same fmaf order -- losses, PSNR and every parameter after 12 steps are bit-identical."""
+    from oracle import cpu_ref
+    res = []
+    for cache in (False, True):
+        torch.manual_seed(1)
+        gen = orn.model.Generator(embed_length=80, stem_dim_num='32_1', fc_hw_dim='2_3_26', expansion=1, num_blocks=1, norm='none',
+                                  act='swish', bias=True, reduction=2, conv_type='conv', stride_list=[5, 2, 2], sin_res=True,
+                                  lower_width=96, sigmoid=False, deploy=False, branch_type='ERB')
+        eng = orn.engine.TrainEngine(gen, loss_type='Fusion6', beta=0.5, precision=prec, target_cache=cache)
+        frames = cpu_ref.synthetic_video(5, eng.out_hw[0], eng.out_hw[1], seed=5)
+        embeds = cpu_ref.positional_encoding(torch.tensor([k / 5 for k in range(5)]), 1.25, 40)
+        eng.set_video(frames, embeds)
+        assert (eng.tstats is not None) == cache
+        eng.set_schedule([(k % 5, k + 1, 5e-4) for k in range(12)])
+        eng.run(12, graph=True)
+        torch.cuda.synchronize()
+        res.append((eng.stats(12).clone(), eng.params.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
