@@ -157,6 +157,47 @@ struct OrnStepCur {
     int32_t pad[2];
 };
 
+// Last stage of the loss (fixed-order sum of the per-tile partials -> loss, L1, MSE, SSIM, PSNR, the stats ring, the non-finite
+// flag): one work-group, needed only by Adam at the end of the step -- so the 16-bit engine lets it ride on the head's backward
+// launch instead of paying a launch of its own (5 us + a boundary).
+struct OrnLossFinalJob {
+    const float *part_ssim; int n_ssim; const float *part_l1; int n_l1;    // n_l1 == 0: no job
+    double n_elem, n_map; int loss_type; float loss_scale;
+    float *stats; const OrnStepCur *cur; float *ring; OrnScaleState *sc;
+};
+// every thread of the work-group calls it (barriers inside); sd: 3 * blockDim.x doubles of LDS; blockDim.x a power of two
+__device__ __forceinline__ void orn_loss_finalize_block(const OrnLossFinalJob &j, double *sd)
+{
+    const int t = threadIdx.x, nt = blockDim.x;
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int i = t; i < j.n_l1; i += nt) { a += (double)j.part_l1[2 * i]; b += (double)j.part_l1[2 * i + 1]; }
+    for (int i = t; i < j.n_ssim; i += nt) c += (double)j.part_ssim[i];
+    sd[t] = a; sd[nt + t] = b; sd[2 * nt + t] = c;
+    __syncthreads();
+    for (int s = nt >> 1; s > 0; s >>= 1) {
+        if (t < s) { sd[t] += sd[t + s]; sd[nt + t] += sd[nt + t + s]; sd[2 * nt + t] += sd[2 * nt + t + s]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const float l1 = (float)(sd[0] / j.n_elem);
+        const float mse = (float)(sd[nt] / j.n_elem);
+        const float ss = (j.loss_type == 2 /* ORN_LOSS_FUSION6 */) ? (float)(sd[2 * nt] / j.n_map) : 0.f;
+        float loss;
+        if (j.loss_type == 0 /* L2 */) loss = mse;
+        else if (j.loss_type == 1 /* L1 */) loss = l1;
+        else loss = 0.7f * l1 + 0.3f * (1.0f - ss);
+        orn_flag_nonfinite(j.sc, loss);                // a NaN / inf forward pass: no update from this step
+        const float psnr = -10.0f * log10f(mse);
+        j.stats[0] = loss * j.loss_scale; j.stats[1] = l1; j.stats[2] = mse; j.stats[3] = ss; j.stats[4] = psnr;
+        j.stats[5] = 0.f; j.stats[6] = 0.f; j.stats[7] = 0.f;
+        if (j.ring) {                                  // engine: publish into the per-step ring (slot from the cursor)
+            float *r = j.ring + (size_t)j.cur->slot * 8;
+            r[0] = loss * j.loss_scale; r[1] = l1; r[2] = mse; r[3] = ss; r[4] = psnr;
+            r[5] = j.cur->lr; r[6] = (float)j.cur->frame; r[7] = (float)j.cur->step;
+        }
+    }
+}
+
 // ---- internal cross-file entry points (not exported) -----------------------------------------
 // Generic deterministic column reduce: out[j] = sum_{i<rows} in[i*ld + j], fixed order.
 int orn_launch_reduce_rows(const float *in, int rows, size_t ld, size_t n, float *out, hipStream_t st);

@@ -1323,8 +1323,13 @@ template <int NQ>
 __global__ void __launch_bounds__(256)
 k_head_bwd_nhwc_bf16(const h16 *__restrict__ z, const float *__restrict__ w, const float *__restrict__ out,
                      const float *__restrict__ dout, int H, int W, int sigmoid, int sp, float gs_up, h16 *__restrict__ dypad,
-                     float *__restrict__ partial, const OrnScaleState *sc)
+                     float *__restrict__ partial, const OrnScaleState *sc, OrnLossFinalJob fin, int nblk)
 {
+    if ((int)blockIdx.x >= nblk) {                   // rider: the loss's finalize stage (needed by Adam only)
+        __shared__ double fsd[3 * 256];
+        orn_loss_finalize_block(fin, fsd);
+        return;
+    }
     if (sc) gs_up = sc->gs;                          // engine: the scale lives in device memory (dynamic loss scaling)
     constexpr int C = NQ * 32;
     __shared__ float sw[3 * C];
@@ -1342,7 +1347,7 @@ k_head_bwd_nhwc_bf16(const h16 *__restrict__ z, const float *__restrict__ w, con
     const int Wp = W / sp + 2, Cp = C * sp * sp;
     // software pipeline: the next pixel's operands (3 x 16 B of z, out / dout) are requested before this pixel's ~500
     // VALU instructions, so each iteration no longer starts with an exposed HBM round trip
-    const size_t pstep = (size_t)gridDim.x * 64;
+    const size_t pstep = (size_t)nblk * 64;
     size_t pix = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2);
     h16x8 vn[NQ];
     float on[3], gn[3];
@@ -1448,18 +1453,22 @@ int orn_head_bwd_bf16_blocks(int H, int W) { const int b = orn_cdiv((long)H * W,
 
 // gs_up: gradient scale carried by dypad (1 for bf16, 2^20 for fp16); dw/db are un-scaled here
 int orn_launch_head_bwd_bf16(const h16 *z, const float *w, const float *out, const float *dout, int C, int H, int W, int sigmoid,
-                             int sp, float gs_up, h16 *dypad, float *dw, float *db, float *ws, hipStream_t st, const OrnScaleState *sc = nullptr)
+                             int sp, float gs_up, h16 *dypad, float *dw, float *db, float *ws, hipStream_t st, const OrnScaleState *sc = nullptr,
+                             const OrnLossFinalJob *fin = nullptr)
 {
     ORN_REQUIRE(C == 96 || C == 32 || C == 64 || C == 128, "head_bwd_bf16: unsupported C=%d", C);
     ORN_REQUIRE(H % sp == 0 && W % sp == 0, "head_bwd_bf16: H,W not divisible by stride");
     int blocks = orn_cdiv((long)H * W, 64);
     if (blocks > HB_BLOCKS) blocks = HB_BLOCKS;
     float *partial = ws, *red = ws + (size_t)HB_BLOCKS * (3 * C + 3);
+    OrnLossFinalJob fj = {};
+    if (fin) fj = *fin;
+    const int nfin = (fin && fin->n_l1 > 0) ? 1 : 0;
     switch (C) {
-    case 32: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<1>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, gs_up, dypad, partial, sc); break;
-    case 64: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<2>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, gs_up, dypad, partial, sc); break;
-    case 96: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<3>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, gs_up, dypad, partial, sc); break;
-    default: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<4>, dim3(blocks), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, gs_up, dypad, partial, sc); break;
+    case 32: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<1>, dim3(blocks + nfin), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, gs_up, dypad, partial, sc, fj, blocks); break;
+    case 64: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<2>, dim3(blocks + nfin), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, gs_up, dypad, partial, sc, fj, blocks); break;
+    case 96: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<3>, dim3(blocks + nfin), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, gs_up, dypad, partial, sc, fj, blocks); break;
+    default: hipLaunchKernelGGL(k_head_bwd_nhwc_bf16<4>, dim3(blocks + nfin), dim3(256), 0, st, z, w, out, dout, H, W, sigmoid, sp, gs_up, dypad, partial, sc, fj, blocks); break;
     }
     ORN_LAUNCH_CHECK("head_bwd_bf16");
     if (!dw) return 0;                  // deferred: rides along orn_launch_wgrad_bf16_batch (OrnHeadFinish)
@@ -1487,8 +1496,8 @@ static int a_to_nchw_f32(const float *src, int C, int Cp, int H, int W, int nsla
 static int a_head_fwd(const void *z, const float *w, const float *b, int C, size_t HW, int sigmoid, float *out, hipStream_t st)
 { return orn_launch_head_fwd_bf16((const h16 *)z, w, b, C, HW, sigmoid, out, st); }
 static int a_head_bwd(const void *z, const float *w, const float *out, const float *dout, int C, int H, int W, int sigmoid, int sp,
-                      float gs_up, void *dypad, float *dw, float *db, float *ws, hipStream_t st, const OrnScaleState *sc)
-{ return orn_launch_head_bwd_bf16((const h16 *)z, w, out, dout, C, H, W, sigmoid, sp, gs_up, (h16 *)dypad, dw, db, ws, st, sc); }
+                      float gs_up, void *dypad, float *dw, float *db, float *ws, hipStream_t st, const OrnScaleState *sc, const OrnLossFinalJob *fin)
+{ return orn_launch_head_bwd_bf16((const h16 *)z, w, out, dout, C, H, W, sigmoid, sp, gs_up, (h16 *)dypad, dw, db, ws, st, sc, fin); }
 
 const OrnHalfOps ops = {a_conv_fwd, a_conv_dgrad, orn_wgrad_bf16_ws_floats, a_wgrad, orn_launch_wgrad_bf16_batch, orn_launch_wgrad_reduce_all, orn_launch_prep_weights_bf16_all, a_to_nhwc,
                         a_to_nchw_f32, orn_dgrad_f32_slabs, a_head_fwd, orn_head_bwd_bf16_ws_floats, orn_head_bwd_bf16_blocks, a_head_bwd};

@@ -500,12 +500,14 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
     }
     const int *fidx = &cur->frame;
     ORN_TRY(forward(e, embeds, fidx, true, st));
-    ORN_TRY(orn_launch_loss(e->img, frames, fidx, 3 * HWo, 1, 3, e->Hout, e->Wout, d.loss_type, 1.0f, e->stats, e->dimg,
-                            e->loss_ws, st, cur, stats_out, e->sc, d.loss_type == ORN_LOSS_FUSION6 ? e->tstats : nullptr));
     const int nl = d.n_layers, ff = e->ff;
+    OrnLossFinalJob fin = {};
+    ORN_TRY(orn_launch_loss(e->img, frames, fidx, 3 * HWo, 1, 3, e->Hout, e->Wout, d.loss_type, 1.0f, e->stats, e->dimg,
+                            e->loss_ws, st, cur, stats_out, e->sc, d.loss_type == ORN_LOSS_FUSION6 ? e->tstats : nullptr,
+                            ff < nl ? &fin : nullptr));     // 16-bit engine: the finalize stage rides on the head's backward launch
     if (ff < nl)
         ORN_TRY(e->ops->head_bwd(e->L[nl - 1].zb, P + d.head_w, e->img, e->dimg, e->Cn_last, e->Hout, e->Wout, d.sigmoid,
-                                 d.layer[nl - 1].s, e->gs, e->L[nl - 1].dypad, nullptr, nullptr, e->head_ws, st, e->sc));   // dW / db: finished with the wgrad batch
+                                 d.layer[nl - 1].s, e->gs, e->L[nl - 1].dypad, nullptr, nullptr, e->head_ws, st, e->sc, &fin));   // dW / db: finished with the wgrad batch
     else
         ORN_TRY(orn_launch_head_bwd(e->L[nl - 1].a, P + d.head_w, e->img, e->dimg, 1, e->Cn_last, HWo, d.sigmoid, e->L[nl - 1].da,
                                     G + d.head_w, G + d.head_b, e->scratch, st));

@@ -96,7 +96,8 @@ int orn_loss_init();
 int orn_launch_loss(const float *pred, const float *target, const int *frame_idx, size_t frame_stride, int B, int Ch,
                     int H, int W, int loss_type, float loss_scale, float *stats, float *dpred, float *ws,
                     hipStream_t st, const OrnStepCur *cur = nullptr, float *ring = nullptr, OrnScaleState *sc = nullptr,
-                    const float *tstats = nullptr);   // tstats: orn_loss_target_stats of the SAME frame table (Fusion6; indexed by *frame_idx)
+                    const float *tstats = nullptr,    // tstats: orn_loss_target_stats of the SAME frame table (Fusion6; indexed by *frame_idx)
+                    OrnLossFinalJob *defer = nullptr);   // defer: the finalize stage is returned as a job instead of launched
 
 // orn_conv_bf16.hip: the 16-bit MFMA fast path (channels-last buffers, see the file header).  The file is built
 // twice (bf16 and, with -DORN_FP16, IEEE half); the engine reaches either build through this type-erased table.
@@ -127,7 +128,8 @@ struct OrnHalfOps {
     size_t (*head_bwd_ws_floats)(int C);
     int (*head_bwd_blocks)(int H, int W);
     int (*head_bwd)(const void *z, const float *w, const float *out, const float *dout, int C, int H, int W, int sigmoid, int sp,
-                    float gs_up, void *dypad, float *dw, float *db, float *ws, hipStream_t st, const OrnScaleState *sc);   // sc: gs from the device state
+                    float gs_up, void *dypad, float *dw, float *db, float *ws, hipStream_t st, const OrnScaleState *sc,
+                    const OrnLossFinalJob *fin);   // sc: gs from the device state; fin (optional): the loss's finalize stage as one more work-group
 };
 const OrnHalfOps *orn_half_ops_bf16();
 const OrnHalfOps *orn_half_ops_f16();

@@ -343,44 +343,11 @@ __global__ void __launch_bounds__(256) k_loss_grad(LossP q)
     }
 }
 
-// One block; fixed-order strided partial sums in double, then a fixed tree.
-__global__ void __launch_bounds__(1024)
-k_loss_finalize(const float *__restrict__ part_ssim, int n_ssim, const float *__restrict__ part_l1, int n_l1,
-                double n_elem, double n_map, int loss_type, float loss_scale, float *__restrict__ stats,
-                const OrnStepCur *__restrict__ cur, float *__restrict__ ring, OrnScaleState *sc)
+// One block; fixed-order strided partial sums in double, then a fixed tree (orn_common.h: orn_loss_finalize_block).
+__global__ void __launch_bounds__(256) k_loss_finalize(OrnLossFinalJob j)
 {
-    __shared__ double sd[3][1024];
-    const int t = threadIdx.x;
-    double a = 0.0, b = 0.0, c = 0.0;
-    for (int i = t; i < n_l1; i += 1024) { a += (double)part_l1[2 * i]; b += (double)part_l1[2 * i + 1]; }
-    for (int i = t; i < n_ssim; i += 1024) c += (double)part_ssim[i];
-    sd[0][t] = a; sd[1][t] = b; sd[2][t] = c;
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-        if (t < s) { sd[0][t] += sd[0][t + s]; sd[1][t] += sd[1][t + s]; sd[2][t] += sd[2][t + s]; }
-        __syncthreads();
-    }
-    if (t == 0) {
-        const float l1 = (float)(sd[0][0] / n_elem);
-        const float mse = (float)(sd[1][0] / n_elem);
-        const float ss = (loss_type == ORN_LOSS_FUSION6) ? (float)(sd[2][0] / n_map) : 0.f;
-        float loss;
-        if (loss_type == ORN_LOSS_L2) loss = mse;
-        else if (loss_type == ORN_LOSS_L1) loss = l1;
-        else loss = 0.7f * l1 + 0.3f * (1.0f - ss);
-        orn_flag_nonfinite(sc, loss);                // a NaN / inf forward pass: no update from this step
-        stats[0] = loss * loss_scale;
-        stats[1] = l1;
-        stats[2] = mse;
-        stats[3] = ss;
-        stats[4] = -10.0f * log10f(mse);
-        stats[5] = 0.f; stats[6] = 0.f; stats[7] = 0.f;
-        if (ring) {                                  // engine: publish into the per-step ring (slot from the cursor)
-            float *r = ring + (size_t)cur->slot * 8;
-            r[0] = loss * loss_scale; r[1] = l1; r[2] = mse; r[3] = ss; r[4] = stats[4];
-            r[5] = cur->lr; r[6] = (float)cur->frame; r[7] = (float)cur->step;
-        }
-    }
+    __shared__ double sd[3 * 256];
+    orn_loss_finalize_block(j, sd);
 }
 
 static bool g_gauss_ready = false;
@@ -442,7 +409,7 @@ int orn_loss_init() { ORN_TRY(ensure_gauss()); return ensure_fusion6_lds(); }
 
 int orn_launch_loss(const float *pred, const float *target, const int *frame_idx, size_t frame_stride, int B, int Ch,
                     int H, int W, int loss_type, float loss_scale, float *stats, float *dpred, float *ws,
-                    hipStream_t st, const OrnStepCur *cur, float *ring, OrnScaleState *sc, const float *tstats)
+                    hipStream_t st, const OrnStepCur *cur, float *ring, OrnScaleState *sc, const float *tstats, OrnLossFinalJob *defer)
 {
     ORN_REQUIRE(loss_type == ORN_LOSS_L2 || loss_type == ORN_LOSS_L1 || loss_type == ORN_LOSS_FUSION6,
                 "loss: unsupported loss_type %d", loss_type);
@@ -474,8 +441,10 @@ int orn_launch_loss(const float *pred, const float *target, const int *frame_idx
         else { if (gd) hipLaunchKernelGGL((k_loss_grad<ORN_LOSS_L1, true>), gr, bl, 0, st, q); else hipLaunchKernelGGL((k_loss_grad<ORN_LOSS_L1, false>), gr, bl, 0, st, q); }
     }
     ORN_LAUNCH_CHECK("loss");
-    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, st, q.part_ssim, loss_type == ORN_LOSS_FUSION6 ? n_tiles : 0, q.part_l1, n_tiles, n,
-                       (double)g.nmap, loss_type, loss_scale, stats, cur, ring, sc);
+    const OrnLossFinalJob fj = {q.part_ssim, loss_type == ORN_LOSS_FUSION6 ? n_tiles : 0, q.part_l1, n_tiles, n, (double)g.nmap, loss_type,
+                                loss_scale, stats, cur, ring, sc};
+    if (defer) { *defer = fj; return 0; }              // the caller runs it as a rider of a later launch
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, st, fj);
     ORN_LAUNCH_CHECK("loss_finalize");
     return 0;
 }

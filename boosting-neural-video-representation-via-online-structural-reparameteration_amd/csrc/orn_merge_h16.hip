@@ -71,29 +71,34 @@ struct MhProb {
 #define MH_KB 8                   // MFMA k-steps per software-pipeline batch
 struct MhGroup { int n; int tile_start[MH_MAXP + 1]; MhProb p[MH_MAXP]; };
 
+// One work-group = one 32x32 output tile; its four waves split K (a quarter each, whole 16-deep MFMA steps) and their partial
+// tiles are summed through LDS in wave order (fixed: run-to-run identical).  Rounds 1-2 gave every wave a tile of its own and
+// the whole K: the launch lasted as long as one wave's chain of dependent load batches (7 for K = 864, each a round trip to
+// HBM for operands written a launch ago), ~27 us for 3 GFLOP.
 __global__ void __launch_bounds__(256) k_mgemm_h16(const MhGroup *__restrict__ g, int total_tiles)
 {
-    // wave index through readfirstlane: the tile, its problem and K become provably wave-uniform (scalar loads of the
-    // table, scalar branches around the MFMA batches)
+    __shared__ float part[4][16][64];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, l31 = lane & 31, hh = lane >> 5;
-    const int tile = blockIdx.x * 4 + wave;
-    if (tile >= total_tiles) return;
+    const int tile = blockIdx.x;
     int pi = 0;
     while (pi + 1 < g->n && tile >= g->tile_start[pi + 1]) ++pi;
     const MhProb &p = g->p[pi];
     const int local = tile - g->tile_start[pi];
     const int b = local / p.tiles, r = local - b * p.tiles;
     const int tm = r / p.tiles_n, tn = r - tm * p.tiles_n;
-    const mh16 *ap = p.A + (size_t)b * p.ba + (size_t)(tm * 32 + l31) * p.lda + hh * 8;
-    const mh16 *bp = p.B + (size_t)b * p.bb + (size_t)(tn * 32 + l31) * p.ldb + hh * 8;
+    // this wave's K range: steps [s0, s1) of 16
+    const int nsteps = p.K / 16, per = (nsteps + 3) / 4;
+    const int s0 = min(wave * per, nsteps), s1 = min(s0 + per, nsteps);
+    const mh16 *ap = p.A + (size_t)b * p.ba + (size_t)(tm * 32 + l31) * p.lda + hh * 8 + s0 * 16;
+    const mh16 *bp = p.B + (size_t)b * p.bb + (size_t)(tn * 32 + l31) * p.ldb + hh * 8 + s0 * 16;
     mf32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const int K = p.K;
+    const int K = (s1 - s0) * 16;
     int k = 0;
     // MH_KB k-steps (128 deep) per iteration: the 16 fragment loads of the next iteration are in flight under this
-    // iteration's MFMAs -- the kernel is bound by the latency chain of a wave's K loop, not by MFMA or bandwidth
+    // iteration's MFMAs
     mh16x8 fa[MH_KB], fb[MH_KB];
     constexpr int KD = MH_KB * 16;
     if (K >= KD) {
@@ -131,25 +136,35 @@ __global__ void __launch_bounds__(256) k_mgemm_h16(const MhGroup *__restrict__ g
         for (int j = 0; j < MH_KB; ++j)
             if (j < nt) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ta[j], tb[j], acc, 0, 0, 0);
     }
+    // partial tiles -> LDS; wave w then owns accumulator registers 4w .. 4w+3 (rows 8w + {0..3} + 4 hh of the tile)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part[wave][i][lane] = acc[i];
+    __syncthreads();
+    float sum[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int reg = 4 * wave + i;
+        sum[i] = ((part[0][reg][lane] + part[1][reg][lane]) + part[2][reg][lane]) + part[3][reg][lane];
+    }
     // D: column n = tn*32 + l31 (B row), rows m = tm*32 + (reg&3) + 8*(reg>>2) + 4*hh
     const int n = tn * 32 + l31;
     if (n >= p.N) return;
     if (p.mode == 0) {
         float *C = p.C + (size_t)b * p.bc + (size_t)n * p.scn;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int m = tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-            if (m < p.M) C[(size_t)m * p.scm] = acc[reg] * p.so;
+        for (int i = 0; i < 4; ++i) {
+            const int reg = 4 * wave + i, m = tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+            if (m < p.M) C[(size_t)m * p.scm] = sum[i] * p.so;
         }
     } else {
         const int c = n / 9, ij = n - c * 9;
         mh16 *t = p.dtt + (size_t)ij * p.st_t + c;                  // dTt[ij][m][c]
         mh16 *u = p.dtc + (size_t)ij * p.st_c + (size_t)c * p.ldc;   // dTc[ij][c][m]
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int m = tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+        for (int i = 0; i < 4; ++i) {
+            const int reg = 4 * wave + i, m = tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
             if (m < p.M) {
-                const mh16 v = (mh16)acc[reg];                       // = dT * 2^14 (B = G carried the scale)
+                const mh16 v = (mh16)sum[i];                         // = dT * 2^14 (B = G carried the scale)
                 t[(size_t)m * p.ldt] = v;
                 u[m] = v;
             }
@@ -257,9 +272,9 @@ int orn_launch_merge_h16_bwd(const void *dev_tables, const void *host, hipStream
     hipLaunchKernelGGL(k_merge_pack, dim3(H->pack_blocks_grad), dim3(256), 0, st, H->pack, (int)MH_TAB_GRAD);     // G -> Gh, GT
     ORN_LAUNCH_CHECK("merge_pack");
     const MhGroup *g = (const MhGroup *)dev_tables;
-    hipLaunchKernelGGL(k_mgemm_h16, dim3(orn_cdiv(H->tiles[0], 4)), dim3(256), 0, st, g, H->tiles[0]);
+    hipLaunchKernelGGL(k_mgemm_h16, dim3(H->tiles[0]), dim3(256), 0, st, g, H->tiles[0]);
     ORN_LAUNCH_CHECK("mgemm_h16(dW3,dT)");
-    hipLaunchKernelGGL(k_mgemm_h16, dim3(orn_cdiv(H->tiles[1], 4)), dim3(256), 0, st, g + 1, H->tiles[1]);
+    hipLaunchKernelGGL(k_mgemm_h16, dim3(H->tiles[1]), dim3(256), 0, st, g + 1, H->tiles[1]);
     ORN_LAUNCH_CHECK("mgemm_h16(dW2,dW1)");
     return 0;
 }
