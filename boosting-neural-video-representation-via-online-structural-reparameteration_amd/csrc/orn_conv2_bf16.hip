@@ -29,11 +29,16 @@
 #define HNS orn_f16
 typedef _Float16 h16;
 #define MFMA16_H16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define MFMA_H16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 #else
 #define HNS orn_bf16
 typedef __bf16 h16;
 #define MFMA16_H16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define MFMA_H16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 #endif
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+#define PDBG(p_) 0
 typedef __attribute__((ext_vector_type(8))) h16 h16x8;
 typedef __attribute__((ext_vector_type(2))) h16 h16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -50,6 +55,8 @@ __device__ __forceinline__ void c2_sfor(F &&f)
 }
 
 namespace HNS {
+
+#include "orn_wgrad_body.h"
 
 #define C2_TH 8
 #define C2_TW 32
@@ -453,6 +460,25 @@ __global__ void __launch_bounds__(256, 2) k_conv2_nhwc(Conv2P p)
     }
 }
 
+// The dgrad of a block with its OWN wgrad behind it in one launch: the block's weight gradient needs only dy and x of that
+// block, both final before its dgrad starts, and both bodies are four waves at two work-groups per CU.  The dgrad's tiles
+// leave the chip under-filled in their last round (720p: 900 tiles on 512 slots = 1.76 rounds; 230 = 0.45); the wgrad
+// work-groups are dispatched behind them and take the slots as they free up.
+__global__ void __launch_bounds__(256, 2) k_conv2_dgrad_wgrad(Conv2P p, WgradBP wp, int dgrad_blocks)
+{
+    if ((int)blockIdx.x >= dgrad_blocks) {
+        wgrad_body(wp, (int)blockIdx.x - dgrad_blocks);
+        return;
+    }
+    if ((int)blockIdx.x >= p.ptiles) return;          // (the tile count is rounded up to a multiple of 8 for the riders' decode)
+    switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {       // one copy of the body per DMA role (wave-uniform)
+    case 0: c2_body<C2_DGRAD, 0>(p); break;
+    case 1: c2_body<C2_DGRAD, 1>(p); break;
+    case 2: c2_body<C2_DGRAD, 2>(p); break;
+    default: c2_body<C2_DGRAD, 3>(p); break;
+    }
+}
+
 template <int EPI>
 static int c2_launch(const Conv2P &p, int blocks, size_t lds, hipStream_t st, const char *what)
 {
@@ -470,7 +496,8 @@ static int c2_launch(const Conv2P &p, int blocks, size_t lds, hipStream_t st, co
 
 // dgrad of a block whose input image has >= 128 pixel tiles: dx = conv_transpose(dy) x SiLU'(z_prev) into the previous block's
 // dypad.  dypad [H+2][W+2][O], wd [9][96][O] (+ slack: see orn_conv_bf16_wd_elems), O % 32 == 0.
-int orn_launch_dgrad2(const h16 *dypad, const h16 *wd, int H, int W, int O, const h16 *zprev, h16 *dyprev, int sp, hipStream_t st)
+int orn_launch_dgrad2(const h16 *dypad, const h16 *wd, int H, int W, int O, const h16 *zprev, h16 *dyprev, int sp, hipStream_t st,
+                      const WgradBP *wgrad_rider, int wgrad_blocks)
 {
     ORN_REQUIRE(O % C2_CK == 0 && zprev && dyprev && sp >= 1 && sp < 65536 && H % sp == 0 && W % sp == 0 && H < 65536 && W < 65536,
                 "conv_bf16_dgrad: unsupported O=%d sp=%d", O, sp);
@@ -480,6 +507,19 @@ int orn_launch_dgrad2(const h16 *dypad, const h16 *wd, int H, int W, int O, cons
     p.qseg = O / C2_CK;
     p.tiles_w = orn_cdiv(W, C2_TW); p.tiles_h = orn_cdiv(H, C2_TH); p.ptiles = p.tiles_w * p.tiles_h; p.nsplit = 1;
     p.zprev = zprev; p.dyprev = dyprev; p.sp = sp; p.mSp = c2_magic(sp);
+    if (wgrad_rider && wgrad_blocks > 0) {
+        static bool attr_done = false;
+        const size_t lds = C2_LDS > 2 * WB_BUF_BYTES ? C2_LDS : 2 * WB_BUF_BYTES;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute((const void *)k_conv2_dgrad_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { orn_set_error("dgrad2+wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+            attr_done = true;
+        }
+        const int db = (p.ptiles + 7) / 8 * 8;       // the wgrad's XCD-aware decode wants its block range to start on a multiple of 8
+        hipLaunchKernelGGL(k_conv2_dgrad_wgrad, dim3(db + wgrad_blocks), dim3(256), lds, st, p, *wgrad_rider, db);
+        ORN_LAUNCH_CHECK("dgrad2_wgrad_nhwc");
+        return 0;
+    }
     return c2_launch<C2_DGRAD>(p, p.ptiles, C2_LDS, st, "dgrad2_nhwc");
 }
 

@@ -511,6 +511,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
     else
         ORN_TRY(orn_launch_head_bwd(e->L[nl - 1].a, P + d.head_w, e->img, e->dimg, 1, e->Cn_last, HWo, d.sigmoid, e->L[nl - 1].da,
                                     G + d.head_w, G + d.head_b, e->scratch, st));
+    int wgrad_rode[ORN_MAX_LAYERS] = {};
     for (int i = nl - 1; i >= 0; --i) {
         const orn_layer_desc &l = d.layer[i];
         LayerBuf &b = e->L[i];
@@ -523,10 +524,12 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
             if (i > ff) {
                 // few pixel tiles: input-chunk split through fp32 partial slabs in the scratch, finished into dypad
                 float *part = e->ops->dgrad_f32_slabs(l.H, l.W, l.O) > 1 ? e->scratch : nullptr;
+                // (the block's own wgrad rides behind the dgrad tiles where the launch can carry it: wgrad_rode[i])
+                const OrnWgradJob wjob = {b.xpad, b.dypad, l.H, l.W, l.C, l.O, l.s, b.wslab};
                 ORN_TRY(e->ops->conv_dgrad(b.dypad, b.wd, l.H, l.W, l.O, l.C, e->L[i - 1].zb, e->L[i - 1].dypad, d.layer[i - 1].s,
-                                           part, st, l.C));
+                                           part, st, l.C, &wjob, &wgrad_rode[i]));
             } else {
-                ORN_TRY(e->ops->conv_dgrad(b.dypad, b.wd, l.H, l.W, l.O, ORN_FAST_C, nullptr, nullptr, 1, e->dxn, st, l.C));
+                ORN_TRY(e->ops->conv_dgrad(b.dypad, b.wd, l.H, l.W, l.O, ORN_FAST_C, nullptr, nullptr, 1, e->dxn, st, l.C, nullptr, nullptr));
                 if (!e->stage0)
                 ORN_TRY(e->ops->to_nchw_f32(e->dxn, l.C, ORN_FAST_C, l.H, l.W, e->ops->dgrad_f32_slabs(l.H, l.W, l.O), 1.0f / e->gs, dx,
                                             st, e->sc));
@@ -552,9 +555,9 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         // at a time: -37 us per 720p step), followed by ONE launch that reduces every layer's split-K slabs (-27 us).
         OrnWgradJob wj[ORN_MAX_LAYERS];
         int nj = 0;
-        for (int i = nl - 1; i >= ff; --i) {        // largest first
+        for (int i = nl - 1; i >= ff; --i) {        // largest first; blocks whose wgrad rode on their dgrad launch are done
             const orn_layer_desc &l = d.layer[i];
-            wj[nj++] = OrnWgradJob{e->L[i].xpad, e->L[i].dypad, l.H, l.W, l.C, l.O, l.s, e->L[i].wslab};
+            if (!wgrad_rode[i]) wj[nj++] = OrnWgradJob{e->L[i].xpad, e->L[i].dypad, l.H, l.W, l.C, l.O, l.s, e->L[i].wslab};
         }
         const OrnHeadFinish hf = {e->head_ws, e->ops->head_bwd_blocks(e->Hout, e->Wout), e->Cn_last, 1.0f / e->gs, G + d.head_w, G + d.head_b, e->sc};
         if (e->prof) (void)hipEventRecord(e->prof_ev[4 * ORN_MAX_LAYERS], st);

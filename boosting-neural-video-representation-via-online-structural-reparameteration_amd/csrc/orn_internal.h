@@ -114,7 +114,8 @@ struct OrnHalfOps {
     int (*conv_fwd)(const void *xpad, const void *wb, const float *bias_p, int H, int W, int Cin, int O, int s, void *z, void *apad,
                     hipStream_t st, int c_real, OrnHeadFuse *head);   // c_real <= Cin: input channels that are not zero padding; head: optional
     int (*conv_dgrad)(const void *dypad, const void *wd, int H, int W, int O, int C, const void *zprev, void *dyprev, int sp,
-                      float *dx_f32, hipStream_t st, int c_real);   // c_real: output channels that are not zero padding
+                      float *dx_f32, hipStream_t st, int c_real,   // c_real: output channels that are not zero padding
+                      const OrnWgradJob *wgrad, int *wgrad_done);   // wgrad (optional): the block's own wgrad job; *wgrad_done = 1 when this launch carried it
     size_t (*wgrad_ws_floats)(int H, int W, int O);
     int (*wgrad)(const void *xpad, const void *dypad, int H, int W, int C, int O, int s, float gscale, float *slabs, float *dwf,
                  float *dbf, hipStream_t st);
