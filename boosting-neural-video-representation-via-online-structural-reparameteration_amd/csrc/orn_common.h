@@ -29,6 +29,15 @@ void orn_set_error(const char *fmt, ...);
         }                                                                   \
     } while (0)
 
+#define ORN_HIP(expr)                                                       \
+    do {                                                                    \
+        hipError_t e__ = (expr);                                            \
+        if (e__ != hipSuccess) {                                            \
+            orn_set_error("%s: %s", #expr, hipGetErrorString(e__));         \
+            return (int)e__;                                                \
+        }                                                                   \
+    } while (0)
+
 #define ORN_TRY(expr)                 \
     do {                              \
         int rc__ = (expr);            \

@@ -509,7 +509,7 @@ int orn_launch_dgrad2(const h16 *dypad, const h16 *wd, int H, int W, int O, cons
     p.zprev = zprev; p.dyprev = dyprev; p.sp = sp; p.mSp = c2_magic(sp);
     if (wgrad_rider && wgrad_blocks > 0) {
         static bool attr_done = false;
-        const size_t lds = C2_LDS > 2 * WB_BUF_BYTES ? C2_LDS : 2 * WB_BUF_BYTES;
+        const size_t lds = C2_LDS > WB_LDS_BYTES ? C2_LDS : WB_LDS_BYTES;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute((const void *)k_conv2_dgrad_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) { orn_set_error("dgrad2+wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }

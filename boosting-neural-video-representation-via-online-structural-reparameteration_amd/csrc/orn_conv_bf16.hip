@@ -803,7 +803,7 @@ static int wgrad_fill(WgradBP &p, const h16 *xpad, const h16 *dypad, int H, int 
     p.n_otiles = orn_cdiv(O, WB_BO);
     static bool attr_done = false;
     if (!attr_done) {
-        const size_t smem = 2 * WB_BUF_BYTES;
+        const size_t smem = WB_LDS_BYTES;
         hipError_t e = hipFuncSetAttribute((const void *)k_wgrad_nhwc_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_wgrad_nhwc_bf16_all, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) { orn_set_error("wgrad_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
@@ -831,7 +831,7 @@ int orn_launch_wgrad_bf16_batch(int n, const OrnWgradJob *J, hipStream_t st, con
     if (hf) { a.hf = *hf; a.hf_blocks = 3 * hf->C + 3; total += a.hf_blocks; }
     a.w0 = OrnStemW0Job{};
     if (w0) { a.w0 = *w0; total += orn_cdiv(w0->N, 2); }
-    hipLaunchKernelGGL(k_wgrad_nhwc_bf16_all, dim3(total), dim3(256), 2 * WB_BUF_BYTES, st, a);
+    hipLaunchKernelGGL(k_wgrad_nhwc_bf16_all, dim3(total), dim3(256), WB_LDS_BYTES, st, a);
     ORN_LAUNCH_CHECK("wgrad_nhwc_bf16_all");
     return 0;
 }
@@ -843,7 +843,7 @@ int orn_launch_wgrad_bf16(const h16 *xpad, const h16 *dypad, int H, int W, int C
 {
     WgradBP p;
     ORN_TRY(wgrad_fill(p, xpad, dypad, H, W, C, O, s, slabs));
-    hipLaunchKernelGGL(k_wgrad_nhwc_bf16, dim3(3 * p.n_otiles * p.S), dim3(256), 2 * WB_BUF_BYTES, st, p);
+    hipLaunchKernelGGL(k_wgrad_nhwc_bf16, dim3(3 * p.n_otiles * p.S), dim3(256), WB_LDS_BYTES, st, p);
     ORN_LAUNCH_CHECK("wgrad_nhwc_bf16");
     if (!dwf) return 0;                 // deferred: orn_launch_wgrad_reduce_all
     const size_t n = (size_t)9 * O * 96;

@@ -13,6 +13,7 @@
 #define WB_X_INSTR ((WB_TH * WB_XW * 12 + 63) / 64)          /* 13 DMA wave-instructions          */
 #define WB_X_BYTES (WB_X_INSTR * 1024)
 #define WB_BUF_BYTES (WB_DY_BYTES + WB_X_BYTES)
+#define WB_LDS_BYTES (4 * 16384)                         /* dynamic LDS of a wgrad work-group: ring of 4 half-tile buffers */
 
 struct WgradBP {
     const h16 *xpad;    // [H+2][W+2][96]
@@ -24,22 +25,99 @@ struct WgradBP {
     int dbg;            // timing-only ablation flags (tools/probes)
 };
 
-__device__ __forceinline__ h16x8 tr_frag(const unsigned char *base0, const unsigned char *base1)
-{
-    // two transposed 4x16 block reads -> the 8 K-consecutive elements of this lane's row/column
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(base0));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(base1));
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
-    s16x8 v;
-    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-    return __builtin_bit_cast(h16x8, v);
-}
-
-// Both LDS images are filled by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction) into a 2-deep ring:
-// tile t+1 streams in while tile t feeds the matrix core; one barrier per tile; two work-groups per CU.
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"      // the LDS-DMA asm names m0 as clobbered (nothing else in this function uses it)
+// ------------------------------------------------------------------------------------------------------------------------
+// The K loop is a software pipeline (round 3; the first form -- a 2-deep ring of 2-row tiles, `vmcnt(0)` + barrier per tile, fragment
+// reads left to the compiler, which issued each ds_read_b64_tr_b16 pair one or two MFMAs ahead of its use -- is in the git history:
+// L4 alone 189 -> 178 us, the batched launch of the 720p step 194 -> 188.5 us).
+//   K unit = HALF-tile = 1 row x 32 pixels: dy 8 KiB + x 34 px x 192 B (8 KiB reserved) = 16 KiB; ring of 4 = 64 KiB per
+//   work-group, still two work-groups per CU.  A half-tile is 18 MFMAs per wave (2 k-steps x 9 tiles) = 18 "positions".
+//   Position i: read B fragment i+5 (2 transposed reads; fragments live in a 9-slot register ring, fragment f in slot f % 9;
+//   from position 13 on they come from the NEXT half-tile's buffer) | at i % 9 == 2 the next k-step's A fragment |
+//   counted lgkmcnt wait for fragment i (10 or 12 younger reads stay in flight; at most 14 outstanding: the counter has 4 bits) |
+//   MFMA i.  One rendezvous per half-tile, before position 9: `vmcnt(4)` (this wave's 4 pieces of half-tile m+1 have landed,
+//   those of m+2 may fly) + s_barrier; behind it every wave has consumed its fragments of half-tile m-1, so its buffer takes
+//   the 4 DMA pieces of half-tile m+3, one per position 9..12.  No lgkmcnt drain anywhere in the loop.
+//   Every wave issues exactly 4 pieces per half-tile (2 dy, 2 x; the 16th piece of a half-tile lies behind the x patch and
+//   loads the zero pixel) and half-tiles past the end are "loaded" from the zero pixel too: the counts in the waits are
+//   compile-time constants and a position is one basic block.
+#define W2_HB 16384
+#ifndef W2_ABL
+#define W2_ABL 0                 /* tools/probes timing-only ablations (tagged builds): 1 no DMA pieces in the loop, 2 no DMA plan, 4 no B reads, 8 no rendezvous */
+#endif
+#define W2_XOFF 8192
+#define W2_LEAD 5
+struct WFrag { s16x4 lo, hi; };
+__device__ __forceinline__ h16x8 w2_join(const WFrag &f)
+{
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(h16x8, v);
+}
+template <int F>
+__device__ __forceinline__ void w2_read_b(WFrag &f, unsigned baddr)
+{
+    constexpr int half = F / 9, e = F % 9, j = e / 3, c = e % 3;
+    constexpr int off = (16 * half + j) * WB_XB + c * 64;
+    if constexpr ((W2_ABL & 4) != 0) return;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo) : "v"(baddr), "n"(off) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(baddr), "n"(off + 4 * WB_XB) : "memory");
+}
+template <int HALF>
+__device__ __forceinline__ void w2_read_a(WFrag &f, unsigned aaddr)
+{
+    constexpr int off = 16 * HALF * WB_DYB;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo) : "v"(aaddr), "n"(off) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(aaddr), "n"(off + 4 * WB_DYB) : "memory");
+}
+// the wait names the registers it retires as read-write: no MFMA that consumes them can be scheduled above it
+template <int N> __device__ __forceinline__ void w2_wait(WFrag &b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(b.lo), "+v"(b.hi) : "n"(N)); }
+template <int N> __device__ __forceinline__ void w2_wait2(WFrag &b, WFrag &a)
+{
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(b.lo), "+v"(b.hi), "+v"(a.lo), "+v"(a.hi) : "n"(N));
+}
+
+#define W2DMA(sbase_, voff_, ldsaddr_)                                                                          \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                               \
+                 :: "s"(ldsaddr_), "v"(voff_), "s"((const void *)(sbase_)) : "memory", "m0")
+
+struct W2Dma {                 // the DMA front: wave-uniform state of the next half-tile to request
+    int h, tw, left;           // row, tile column, half-tiles still to request
+    int dh, dw;                // S / tiles_w, S % tiles_w
+};
+
+template <int I>
+__device__ __forceinline__ void w2_pos(f32x16 (&acc)[3][3], WFrag (&fb)[9], WFrag (&fa)[2], const unsigned a_cur, const unsigned b_cur,
+                                       const unsigned a_nxt, const unsigned b_nxt, float &bsum)
+{
+    constexpr int FN = I + W2_LEAD;
+    if constexpr (FN < 18) w2_read_b<FN>(fb[FN % 9], b_cur);
+    else w2_read_b<FN - 18>(fb[FN % 9], b_nxt);
+    if constexpr (I == 2) w2_read_a<1>(fa[1], a_cur);
+    if constexpr (I == 11) w2_read_a<0>(fa[0], a_nxt);
+    constexpr int N = 2 * W2_LEAD + ((I % 9 >= 2 && I % 9 <= 7) ? 2 : 0);
+    if constexpr (I % 9 == 0) w2_wait2<N>(fb[I % 9], fa[I / 9]);
+    else w2_wait<N>(fb[I % 9]);
+    const h16x8 a = w2_join(fa[I / 9]);
+    if constexpr (I % 9 == 0) {
+        typedef __attribute__((ext_vector_type(2))) h16 h16v2;
+        const h16v2 ones2 = {(h16)1.0f, (h16)1.0f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const h16v2 a2 = {a[2 * e], a[2 * e + 1]};
+#ifdef ORN_FP16
+            bsum = __builtin_amdgcn_fdot2(a2, ones2, bsum, false);
+#else
+            bsum = __builtin_amdgcn_fdot2_f32_bf16(a2, ones2, bsum, false);
+#endif
+        }
+    }
+    constexpr int e9 = I % 9, j = e9 / 3, c = e9 % 3;
+    acc[j][c] = MFMA_H16(a, w2_join(fb[I % 9]), acc[j][c]);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 __device__ __forceinline__ void wgrad_body(const WgradBP &p, const int id)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -61,131 +139,126 @@ __device__ __forceinline__ void wgrad_body(const WgradBP &p, const int id)
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][c][r] = 0.f;
-    // dbias rides along: the A fragment holds 8 pixels of one dy channel per lane, so its column sum is four packed
-    // dot products with ones (v_dot2c_f32, fp32 accumulate) that issue under the MFMAs.  (A ones-MFMA in the ti == 1
-    // work-groups made those 11 % longer than their neighbours: -17 us on the last block's launch.)  Every work-group
-    // computes it -- no branch in the K loop -- and the ti == 1 ones store it.
-    float bsum = 0.f;
-    typedef __attribute__((ext_vector_type(2))) h16 h16v2;
-    const h16v2 ones2 = {(h16)1.0f, (h16)1.0f};
+    float bsum = 0.f;              // dbias = column sums of the dy fragment (v_dot2c under the MFMAs); the ti == 1 work-groups store it
     const bool do_bias = (ti == 1);
 
-    // per-lane transposed-read offsets (pixel part is added per K slice).  dy: this lane's pixels all have
-    // (pixel & 3) == lq, so the XOR swizzle is a per-lane constant.
-    const int a_chunk = uwave * 4 + 2 * (g & 1) + (lp >> 1);
-    const int a_off = (8 * (g >> 1) + lq) * WB_DYB + ((a_chunk ^ (lq << 2)) * 16) + (lp & 1) * 8;
-    const int b_off = (8 * (g >> 1) + lq) * WB_XB + (16 * (g & 1) + 4 * lp) * 2;
-
-    // DMA plan of this wave: 4 dy instructions (64 pixels x 16 chunks / 4 waves) + up to 4 x instructions
-    constexpr int DY_PW = (WB_DY_BYTES / 1024) / 4;          // 4
-    constexpr int X_PW = (WB_X_INSTR + 3) / 4;               // 4 (13 instructions over 4 waves)
-    int dy_px[DY_PW], dy_c[DY_PW], x_px[X_PW], x_c[X_PW];
-#pragma unroll
-    for (int k = 0; k < DY_PW; ++k) {
-        const int L = (uwave + 4 * k) * 64 + lane;           // linear 16-byte slot
-        dy_px[k] = L >> 4;
-        dy_c[k] = (L & 15) ^ ((dy_px[k] & 3) << 2);          // logical chunk stored at this slot
-    }
-#pragma unroll
-    for (int k = 0; k < X_PW; ++k) {
-        const int L = (uwave + 4 * k) * 64 + lane;
-        x_px[k] = L / 12;
-        x_c[k] = L - x_px[k] * 12;
-    }
-    // The LDS-DMA is issued through inline asm: behind the BUILTIN the compiler (which sees an LDS store it cannot tell apart
-    // from the buffer being read) puts `s_waitcnt vmcnt(0)` in front of the first fragment read of the CURRENT tile -- the wave
-    // then waits for the tile it has just requested before it starts the one it holds, and the 2-deep ring prefetches nothing.
-    // The one wait this ring needs is the explicit one at the top of the loop.
     const unsigned wlds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
-#define WDMA16(gptr_, ldsoff_)                                                                                  \
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"   /* (one wait state between the M0 write and its use) */ \
-                 :: "s"(wlds0 + (unsigned)(ldsoff_)), "v"((const void *)(gptr_)) : "memory", "m0")
-    // same, source = wave-uniform base (SGPR pair) + per-lane 32-bit byte offset
-#define WDMA16S(sbase_, voff_, ldsoff_)                                                                         \
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                               \
-                 :: "s"(wlds0 + (unsigned)(ldsoff_)), "v"(voff_), "s"((const void *)(sbase_)) : "memory", "m0")
-    // Interior tiles (every pixel of the tile inside the image: all but a ragged last column / row of tiles) take their
-    // addresses from per-lane offsets computed ONCE relative to the tile origin; the general form below redoes the index
-    // arithmetic and the bounds tests per piece -- ~25 vector instructions x 8 pieces per tile against 36 MFMAs.
-    unsigned dy_loff[DY_PW], x_loff[X_PW];
-#pragma unroll
-    for (int k = 0; k < DY_PW; ++k)
-        dy_loff[k] = (unsigned)(((dy_px[k] / WB_TW + 1) * (W + 2) + (dy_px[k] & (WB_TW - 1)) + 1) * O + o0 + dy_c[k] * 8) * 2u;
-#pragma unroll
-    for (int k = 0; k < X_PW; ++k) {
-        const int r = x_px[k] / WB_XW, c = x_px[k] - r * WB_XW;
-        x_loff[k] = x_px[k] < WB_TH * WB_XW ? (unsigned)(((r + ti) * (W + 2) + c) * 96 + x_c[k] * 8) * 2u : 0u;   // slots behind the patch: never read
-    }
-#define WDMA_TILE(kt_, buf_)                                                                                    \
-    {                                                                                                           \
-        const int th_ = (kt_) / p.tiles_w, tw_ = (kt_) - th_ * p.tiles_w;                                       \
-        const int h0_ = th_ * WB_TH, w0_ = tw_ * WB_TW;                                                         \
-        if (h0_ + WB_TH <= H && w0_ + WB_TW <= W && !(PDBG(p) & 1)) {                                           \
-            const h16 *dyb_ = p.dypad + ((size_t)h0_ * (W + 2) + w0_) * O;                                      \
-            const h16 *xb_ = p.xpad + ((size_t)h0_ * (W + 2) + w0_) * 96;                                       \
-            _Pragma("unroll") for (int k = 0; k < DY_PW; ++k)                                                   \
-                WDMA16S(dyb_, dy_loff[k], (buf_) * WB_BUF_BYTES + (uwave + 4 * k) * 1024);                      \
-            _Pragma("unroll") for (int k = 0; k < X_PW; ++k)                                                    \
-                if (uwave + 4 * k < WB_X_INSTR)                                                                 \
-                    WDMA16S(xb_, x_loff[k], (buf_) * WB_BUF_BYTES + WB_DY_BYTES + (uwave + 4 * k) * 1024);      \
-        } else {                                                                                                \
-        _Pragma("unroll") for (int k = 0; k < DY_PW; ++k) {                                                     \
-            const int gh = h0_ + dy_px[k] / WB_TW, gw = w0_ + (dy_px[k] & (WB_TW - 1));                         \
-            const bool ok = gh < H && gw < W && !(PDBG(p) & 1);                                                   \
-            const h16 *src = ok ? p.dypad + ((size_t)(gh + 1) * (W + 2) + (gw + 1)) * O + o0 + dy_c[k] * 8      \
-                                : p.dypad + dy_c[k] * 8; /* border pixel (0,0): zeros */                        \
-            WDMA16(src, (buf_) * WB_BUF_BYTES + (uwave + 4 * k) * 1024);                                        \
-        }                                                                                                       \
-        _Pragma("unroll") for (int k = 0; k < X_PW; ++k) {                                                      \
-            if (uwave + 4 * k < WB_X_INSTR) {                                                                   \
-                const int r = x_px[k] / WB_XW, c = x_px[k] - r * WB_XW;                                         \
-                const int gh = h0_ + r + ti, gw = w0_ + c;                                                      \
-                const bool ok = x_px[k] < WB_TH * WB_XW && gh < H + 2 && gw < W + 2 && !(PDBG(p) & 1);            \
-                const h16 *src = ok ? p.xpad + ((size_t)gh * (W + 2) + gw) * 96 + x_c[k] * 8 : p.xpad + x_c[k] * 8; \
-                WDMA16(src, (buf_) * WB_BUF_BYTES + WB_DY_BYTES + (uwave + 4 * k) * 1024);                      \
-            }                                                                                                   \
-        }                                                                                                       \
-        }                                                                                                       \
-    }
+    // per-lane transposed-read addresses inside a half-tile buffer.  dy: this lane's pixels all have (pixel & 3) == lq, so the
+    // XOR swizzle is a per-lane constant.
+    const int a_chunk = uwave * 4 + 2 * (g & 1) + (lp >> 1);
+    const unsigned a_lds = wlds0 + (8 * (g >> 1) + lq) * WB_DYB + ((a_chunk ^ (lq << 2)) * 16) + (lp & 1) * 8;
+    const unsigned b_lds = wlds0 + W2_XOFF + (8 * (g >> 1) + lq) * WB_XB + (16 * (g & 1) + 4 * lp) * 2;
 
-    int buf = 0;
-    if (sidx < p.n_ktiles) WDMA_TILE(sidx, 0)
-    for (int kt = sidx; kt < p.n_ktiles; kt += p.S) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt have landed
-        __builtin_amdgcn_s_barrier();                         // ... everyone's have; everyone is done with tile kt - S
-        if (kt + p.S < p.n_ktiles) WDMA_TILE(kt + p.S, buf ^ 1)
-        const unsigned char *dys = smem + buf * WB_BUF_BYTES;
-        const unsigned char *xs = dys + WB_DY_BYTES;
+    // DMA plan: pieces q = uwave, uwave + 4 of the 8 dy instructions (16-byte slot L = 64 q + lane: pixel L >> 4, chunk L & 15)
+    // and of the 8 x instructions (pixel L / 12, chunk L % 12; pixels >= 34 lie behind the patch).  Interior half-tiles take
+    // a wave-uniform base + these per-lane byte offsets; ragged ones (last tile column) and the filler loads recompute them.
+    unsigned loff[4];
 #pragma unroll
-        for (int r = 0; r < WB_TH; ++r)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const unsigned char *ap = dys + (r * WB_TW + 16 * half) * WB_DYB + a_off;
-                const h16x8 a = tr_frag(ap, ap + 4 * WB_DYB);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const h16v2 a2 = {a[2 * e], a[2 * e + 1]};
-#ifdef ORN_FP16
-                    bsum = __builtin_amdgcn_fdot2(a2, ones2, bsum, false);
-#else
-                    bsum = __builtin_amdgcn_fdot2_f32_bf16(a2, ones2, bsum, false);
-#endif
-                }
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const unsigned char *bp = xs + (r * WB_XW + 16 * half + j) * WB_XB + b_off;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const h16x8 b = tr_frag(bp + c * 64, bp + c * 64 + 4 * WB_XB);
-                        acc[j][c] = MFMA_H16(a, b, acc[j][c]);
-                    }
-                }
-            }
-        buf ^= 1;
+    for (int k = 0; k < 2; ++k) {
+        const int L = (uwave + 4 * k) * 64 + lane, px = L >> 4, cc = (L & 15) ^ ((px & 3) << 2);
+        loff[k] = (unsigned)((px + 1) * O + o0 + cc * 8) * 2u;
+        const int Lx = (uwave + 4 * k) * 64 + lane, pxx = Lx / 12, cx = Lx - pxx * 12;
+        loff[2 + k] = pxx < WB_XW ? (unsigned)(pxx * 96 + cx * 8) * 2u : 0u;
     }
-#undef WDMA16
-#undef WDMA16S
-#undef WDMA_TILE
+    const int tiles_w = p.tiles_w;
+    const int NH = H * tiles_w;                                   // half-tiles of the layer; this work-group takes sidx, sidx + S, ..
+    const int n_my = sidx < NH ? (NH - sidx + p.S - 1) / p.S : 0;
+    W2Dma d;
+    d.h = sidx / tiles_w; d.tw = sidx - d.h * tiles_w; d.left = n_my;
+    d.dh = p.S / tiles_w; d.dw = p.S - d.dh * tiles_w;
+    // sources advance by wave-uniform byte strides (64-bit adds on the scalar unit; no multiplies in the loop)
+    const unsigned char *pdy = (const unsigned char *)(p.dypad + ((size_t)(d.h + 1) * (W + 2) + d.tw * WB_TW) * O);
+    const unsigned char *pxs = (const unsigned char *)(p.xpad + ((size_t)(d.h + ti) * (W + 2) + d.tw * WB_TW) * 96);
+    const long pix_step = (long)d.dh * (W + 2) + d.dw * WB_TW;          // pixels from one half-tile of this work-group to its next
+    const long pix_wrap = (long)(W + 2) - (long)tiles_w * WB_TW;          // .. extra when the tile column wraps into the next row
+    const long dy_step = pix_step * O * 2, dy_wrap = pix_wrap * O * 2, x_step = pix_step * 192, x_wrap = pix_wrap * 192;
+
+    auto dma_plan = [&](unsigned (&vo)[4], const unsigned char *&sdy, const unsigned char *&sx) {
+        // source of the next half-tile (or the zero pixel when none is left)
+        const int w0 = d.tw * WB_TW;
+        const bool has = d.left > 0;
+        const bool interior = has && (w0 + WB_TW <= W);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vo[k] = loff[k];
+        sdy = pdy; sx = pxs;
+        if (!interior) {
+            sdy = (const unsigned char *)p.dypad; sx = (const unsigned char *)p.xpad;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int L = (uwave + 4 * k) * 64 + lane, px = L >> 4, cc = (L & 15) ^ ((px & 3) << 2);
+                const bool ok = has && (w0 + px < W);
+                vo[k] = ok ? (unsigned)(((d.h + 1) * (W + 2) + w0 + px + 1) * O + o0 + cc * 8) * 2u : (unsigned)(cc * 8) * 2u;   // else the border pixel (0,0): zeros
+                const int pxx = L / 12, cx = L - pxx * 12;
+                const bool okx = has && pxx < WB_XW && (w0 + pxx < W + 2);
+                vo[2 + k] = okx ? (unsigned)(((d.h + ti) * (W + 2) + w0 + pxx) * 96 + cx * 8) * 2u : (unsigned)(cx * 8) * 2u;
+            }
+        }
+        d.left -= 1;
+        d.tw += d.dw; d.h += d.dh;
+        pdy += dy_step; pxs += x_step;
+        if (d.tw >= tiles_w) { d.tw -= tiles_w; d.h += 1; pdy += dy_wrap; pxs += x_wrap; }
+    };
+    auto dma_piece = [&](const int k, const unsigned (&vo)[4], const unsigned char *sdy, const unsigned char *sx, const unsigned slot_lds) {
+        if (k < 2) W2DMA(sdy, vo[k], slot_lds + (uwave + 4 * k) * 1024);
+        else W2DMA(sx, vo[k], slot_lds + W2_XOFF + (uwave + 4 * (k - 2)) * 1024);
+    };
+
+    // The 16 pieces of a half-tile are dealt one per position over the 16 positions that follow the rendezvous (9..17 of this
+    // half-tile, 0..6 of the next): linear slot n = 4 k + w is piece k of wave w, so the four waves never issue in the same
+    // MFMA gap (all four issuing behind the barrier cost 23 us of the L4 launch: tools/probes/wgrad_variants.sh).  The plan of
+    // the pieces that fall behind the loop's back edge (k = 2 of waves 1..3, k = 3) is carried.
+    auto dma_at = [&](const int lin, const unsigned (&vo)[4], const unsigned char *sdy, const unsigned char *sx, const unsigned slot_lds) {
+        if ((W2_ABL & 1) != 0) return;
+#ifdef W2_SPREAD            /* one piece per position and work-group: measured slower (L4 alone 184.5 vs 180 us), see DESIGN 4.5 */
+        if (lin < 16 && uwave == (lin & 3)) dma_piece(lin >> 2, vo, sdy, sx, slot_lds);
+#else                       /* every wave's piece k at linear slot k: four pieces per gap right behind the rendezvous */
+        if (lin < 4) dma_piece(lin, vo, sdy, sx, slot_lds);
+#endif
+    };
+    // prologue: half-tiles 0, 1 into slots 0, 1 and the first half (linear slots 0..8) of half-tile 2
+    unsigned vo_c[4]; const unsigned char *sdy_c, *sx_c; unsigned dst_c = wlds0 + 2 * W2_HB;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        unsigned vo[4]; const unsigned char *sdy, *sx;
+        dma_plan(vo, sdy, sx);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dma_piece(k, vo, sdy, sx, wlds0 + m * W2_HB);
+    }
+    dma_plan(vo_c, sdy_c, sx_c);
+#pragma unroll
+    for (int lin = 0; lin < 9; ++lin) dma_at(lin, vo_c, sdy_c, sx_c, dst_c);
+    WFrag fb[9], fa[2];
+#ifdef W2_SPREAD
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            // half-tile 0 (this wave's first 4 pieces) has landed
+#else
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
+    __builtin_amdgcn_s_barrier();
+    unsigned a_cur = a_lds, b_cur = b_lds;
+    w2_read_a<0>(fa[0], a_cur);
+    w2_read_b<0>(fb[0], b_cur); w2_read_b<1>(fb[1], b_cur); w2_read_b<2>(fb[2], b_cur); w2_read_b<3>(fb[3], b_cur); w2_read_b<4>(fb[4], b_cur);
+    for (int m = 0; m < n_my; ++m) {
+        const unsigned nxt = (unsigned)((m + 1) & 3) * W2_HB;
+        const unsigned a_nxt = a_lds + nxt, b_nxt = b_lds + nxt;
+#define W2_P(i_)                                                                                                \
+        w2_pos<i_>(acc, fb, fa, a_cur, b_cur, a_nxt, b_nxt, bsum);                                              \
+        dma_at((i_) >= 9 ? (i_) - 9 : (i_) + 9, vo_c, sdy_c, sx_c, dst_c);
+        W2_P(0) W2_P(1) W2_P(2) W2_P(3) W2_P(4) W2_P(5) W2_P(6) W2_P(7) W2_P(8)
+        // rendezvous: half-tile m+1 is in LDS for everyone; everyone is done with half-tile m-1, whose slot takes m+3
+        if constexpr ((W2_ABL & 2) == 0) dma_plan(vo_c, sdy_c, sx_c);
+        dst_c = wlds0 + (unsigned)((m + 3) & 3) * W2_HB;
+        if constexpr ((W2_ABL & 8) == 0) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        W2_P(9) W2_P(10) W2_P(11) W2_P(12) W2_P(13) W2_P(14) W2_P(15) W2_P(16) W2_P(17)
+#undef W2_P
+        a_cur = a_nxt; b_cur = b_nxt;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // the filler loads and the run-ahead reads: drain before the LDS goes away
+    // keep the run-ahead fragments "used" so their reads are not dropped as dead (they are asm volatile: nothing to do)
+
     bsum += __shfl_xor(bsum, 32);                             // the two K halves of the row
     if (o0 + wave * 32 >= O) return;                          // ragged last tile (O % 128 != 0): this wave's 32 channels do not exist
     if (do_bias && hh == 0) p.bias_slabs[(size_t)sidx * O + o0 + wave * 32 + l31] = bsum;
@@ -200,5 +273,6 @@ __device__ __forceinline__ void wgrad_body(const WgradBP &p, const int id)
                 out[((size_t)(ti * 3 + j) * O + o) * 96 + c * 32 + l31] = acc[j][c][reg];
             }
 }
+#undef W2DMA
 
 #pragma clang diagnostic pop
