@@ -13,10 +13,12 @@ OBJ = os.path.join(HERE, 'build' + ('_' + TAG if TAG else ''))
 LIB = os.path.join(HERE, 'liborn' + ('_' + TAG if TAG else '') + '.so')
 EXTRA = os.environ.get('ORN_EXTRA_DEFS', '').split() if TAG else []
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function', '-fvisibility=hidden']
-# Per-file flags.  -fno-slp-vectorize: hipcc's SLP pass packs adjacent fp32 FMAs into v_pk_fma_f32, which issues slower than
-# the two v_fma_f32 it replaces on gfx950 (the VALU-bound Fusion6 kernel: 88 -> 71 us; measured per kernel, round 3)
-FILE_FLAGS = {'orn_loss.hip': ['-fno-slp-vectorize'], 'orn_merge.hip': ['-fno-slp-vectorize']}
+# -fno-slp-vectorize: hipcc's SLP pass packs adjacent fp32 FMAs / multiplies into v_pk_fma_f32 / v_pk_mul_f32 (+ v_mov's to pair the
+# operands), which issue slower than the scalar-per-lane instructions they replace on gfx950 (MI355X_MICROARCH.md: 'an anti-lever');
+# measured per kernel in round 3: Fusion6 88 -> 71 us, head backward 85 -> see DESIGN 4.3
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function', '-fvisibility=hidden', '-fno-slp-vectorize']
+# Per-file flags (none at present)
+FILE_FLAGS = {}
 
 
 def _sources():
