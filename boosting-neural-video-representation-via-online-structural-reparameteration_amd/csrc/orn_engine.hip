@@ -677,6 +677,15 @@ extern "C" int orn_engine_train_steps_graph(orn_engine *e, const float *frames, 
         e->g_slots = n_slots; e->g_stream = st;
     }
     int left = n_steps;
+    // The host needs longer to launch the unrolled graph than the single-step one, and on an idle stream that launch is exposed (the
+    // device waits for it): a call that will launch several graphs starts with ONE single step, and the unrolled launches queue up
+    // behind it while it runs.  (20-step timed region after a synchronise: see DESIGN 6.)
+    static const bool first_single = getenv("ORN_GRAPH_NO_FIRST_SINGLE") == nullptr;
+    if (first_single && left > ORN_GRAPH_UNROLL) {
+        hipError_t rc = hipGraphLaunch(e->graph_exec, st);
+        if (rc != hipSuccess) { orn_set_error("graph: Launch failed: %s", hipGetErrorString(rc)); return (int)rc; }
+        left -= 1;
+    }
     while (left > 0) {
         const bool big = left >= ORN_GRAPH_UNROLL;
         hipError_t rc = hipGraphLaunch(big ? e->graph_exec_u : e->graph_exec, st);
