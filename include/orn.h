@@ -92,7 +92,7 @@ ORN_API int orn_conv3x3_ps_silu_bwd(const float *x, const float *wf, const float
                             size_t ws_bytes, void *stream);
 
 /* ---- A4 on the bf16 MFMA path (fp32 accumulate): same contract as the two calls above for B = 1,
- * C % 96 == 0 (bwd: C == 96), O % 128 == 0.  Inputs/outputs stay fp32 NCHW; the channels-last bf16
+ * C <= 96 (zero-padded to 96 in the staging), O % 32 == 0 and O % (s*s) == 0.  Inputs/outputs stay fp32 NCHW; the channels-last bf16
  * staging (DESIGN.md "data layout") lives in `ws`, which the caller must zero-fill once before the
  * first use (the one-pixel borders are never written).  The engine uses the same kernels without the
  * layout conversions.  fwd: `a` may be NULL (the last block's form: z only), then `z` must not be. */
@@ -105,7 +105,12 @@ ORN_API int orn_conv3x3_ps_silu_bwd_bf16(const float *x, const float *wf, const 
 
 /* The forward conv kernel on the engine's own channels-last bf16 buffers (DESIGN.md "data layout"):
  * xpad [H+2][W+2][C] zero-bordered, wb [9][O'][C], bias_p [O'] (o' = (i*s+j)*Cn + n), z [H*s][W*s][Cn],
- * apad [H*s+2][W*s+2][Cn] or NULL.  This is the dominant kernel bench.py prices against the MFMA roofline. */
+ * apad [H*s+2][W*s+2][Cn] or NULL.  C == 96; O % 32 == 0 (O % 96 == 0 for the two-work-group form the large layers take).
+ * SLACK: the raw entry points of this group tile N by 96 or 128 channels and compute a ragged last tile on whatever lies behind
+ * the operand (results of the missing channels are dropped, never stored).  When O % 128 != 0 the caller must therefore keep
+ * `wb` / `wd` READABLE for 96*C elements past their [9][O'][C] / [9][C][O'] extent and `dypad` for 128 elements past its
+ * [H+2][W+2][O'] extent (any finite or non-finite contents; never written).  The engine and the fp32-layout hooks above pad
+ * their own workspaces; a caller that allocates exact sizes at e.g. O = 864 risks a fault at a page boundary. */
 ORN_API int orn_conv_nhwc_bf16_fwd(const void *xpad, const void *wb, const float *bias_p, int H, int W, int C, int O,
                            int s, void *z, void *apad, void *stream);
 /* the same kernel built for IEEE half (precision 2 of the engine, the mode bench.py's headline runs in): buffers hold fp16 */
@@ -241,7 +246,17 @@ ORN_API int orn_engine_train_steps_graph(orn_engine *e, const float *frames, con
  * model).  The 16-bit gradient tensors of precision 2 travel multiplied by a scale held in device memory (2^20 at creation;
  * 1 for the other precisions).  A step whose gradients (or loss) are not finite leaves parameters and Adam moments untouched
  * and halves the scale; 2000 clean steps double it again up to its initial value.  All of it happens on the device, inside
- * the captured step.  out8 (host): {scale, 1/scale, ceiling, flag, steps skipped, clean steps, halvings, 0}; synchronises. */
+ * the captured step.  out8 (host): {scale, 1/scale, ceiling, flag, steps skipped, clean steps, halvings, 0}; synchronises.
+ * Where this differs from GradScaler:
+ *  - granularity: the flag is read by every step's Adam but cleared (and the scale changed) only where the device-side schedule
+ *    advances, once per graph launch; orn_engine_train_steps_graph replays groups of 4 steps, so the clean steps that FOLLOW an
+ *    overflowing one inside the same group are skipped with it (and counted in `steps skipped`); orn_engine_train_step advances
+ *    every step;
+ *  - `clean steps` is credited when a group is launched, not when it has run (it only paces the re-doubling of the scale);
+ *  - the merge backward of the 16-bit modes rounds the UN-scaled weight gradient times 2^14 to IEEE half: |dWf| > 4 raises the
+ *    same flag, and no loss scale cures that.  Such a fit has diverged; main_train restores the start of the epoch and
+ *    continues in a wider precision (bf16 keeps that operand format, fp32 does not have it);
+ *  - Adam's step count, in the device schedule and in the checkpoint's optimizer entry, excludes skipped steps. */
 ORN_API int orn_engine_scale_state(orn_engine *e, float *out8);
 /* Overrides the live scale (>= 1) and, if gs_max > 0, its ceiling: tests inject an overflowing step this way. */
 ORN_API int orn_engine_set_grad_scale(orn_engine *e, float gs, float gs_max);
