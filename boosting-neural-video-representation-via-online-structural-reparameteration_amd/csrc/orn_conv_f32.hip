@@ -41,15 +41,18 @@ struct ConvP {
 
 // SMALL = 1: 2-row tiles (64 pixels), each wave one 32x32 block -- 4x more work-groups for the small early layers,
 // whose cost is latency, not throughput.
+#ifndef F32_MINB
+#define F32_MINB 2          /* two work-groups per CU: <= 256 VGPRs */
+#endif
 template <int EPI, int SMALL>
-__global__ void __launch_bounds__(256) k_conv3x3_f32(ConvP p)
+__global__ void __launch_bounds__(256, F32_MINB) k_conv3x3_f32(ConvP p)
 {
     constexpr int TH = SMALL ? 2 : CV_TH;
     constexpr int XH = TH + 2;
     constexpr int RW = SMALL ? 1 : 2;          // rows per wave
     constexpr int OBW = SMALL ? 1 : 2;         // 32-channel blocks per wave
-    __shared__ float Xs[CV_CC][XH][CV_XW];
-    __shared__ float Ws[CV_BO][CV_WLD];
+    __shared__ float Xs[2][CV_CC][XH][CV_XW];
+    __shared__ float Ws[2][CV_BO][CV_WLD];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
@@ -72,41 +75,60 @@ __global__ void __launch_bounds__(256) k_conv3x3_f32(ConvP p)
 
     const int r0 = SMALL ? (wave >> 1) : wave * 2;     // first output row of the wave (tile-local)
     const int ob0 = SMALL ? (wave & 1) : 0;            // first 32-channel block of the wave
-    for (int c0 = c_begin; c0 < c_end; c0 += CV_CC) {
-        // ---- stage the input patch (zero padded) and the weight tile: every global load is issued
-        //      before the first LDS write, so one memory latency is exposed per chunk instead of ~30
-        constexpr int XN = (CV_CC * XH * CV_XW + 255) / 256, WN = (CV_BO * CV_CC * 9) / 256;
-        float xr[XN], wr[WN];
+    // Round 3: the K loop is double-buffered.  The global loads of chunk k+1 are issued into registers BEFORE the 36 MFMA k-steps
+    // of chunk k and stored to the other LDS buffer behind them: one barrier per chunk and no exposed memory latency (the first
+    // form staged a chunk, synchronised, computed, synchronised: two work-groups per CU took turns waiting for memory).
+    // Per-thread source offsets of the input patch are chunk-invariant (relative to the chunk's first channel) and computed once.
+    constexpr int XN = (CV_CC * XH * CV_XW + 255) / 256, WN = (CV_BO * CV_CC * 9) / 256;
+    int xoff[XN];                                      // < 0: zero padding (outside the image / the patch)
+#pragma unroll
+    for (int it = 0; it < XN; ++it) {
+        const int idx = t + it * 256;
+        const int c = idx / (XH * CV_XW);
+        const int rem = idx - c * (XH * CV_XW);
+        const int r = rem / CV_XW, xx = rem - r * CV_XW;
+        const int gh = h0 + r - 1, gw = w0 + xx - 1;
+        const bool ok = idx < CV_CC * XH * CV_XW && gh >= 0 && gh < H && gw >= 0 && gw < W;
+        xoff[it] = ok ? (c * H + gh) * W + gw : -1 - c;        // (c kept for the channel-range test of the last chunk)
+    }
+    float xr[XN], wr[WN];
+    auto gload = [&](const int c0) {
+        const float *xc = xb + (size_t)c0 * H * W;
+        const int cleft = c_end - c0;                  // channels of this chunk that exist
 #pragma unroll
         for (int it = 0; it < XN; ++it) {
             const int idx = t + it * 256;
             const int c = idx / (XH * CV_XW);
-            const int rem = idx - c * (XH * CV_XW);
-            const int r = rem / CV_XW, xx = rem - r * CV_XW;
-            const int gh = h0 + r - 1, gw = w0 + xx - 1, gc = c0 + c;
-            xr[it] = 0.f;
-            if (idx < CV_CC * XH * CV_XW && gc < c_end && gh >= 0 && gh < H && gw >= 0 && gw < W)
-                xr[it] = xb[((size_t)gc * H + gh) * W + gw];
+            xr[it] = (xoff[it] >= 0 && c < cleft) ? xc[xoff[it]] : 0.f;
         }
 #pragma unroll
         for (int it = 0; it < WN; ++it) {
             const int idx = t + it * 256;
             const int o = idx / (CV_CC * 9), kk = idx - o * (CV_CC * 9);
-            wr[it] = 0.f;
-            if (o0 + o < p.O && c0 * 9 + kk < c_end * 9) wr[it] = p.w[(size_t)(o0 + o) * C * 9 + (size_t)c0 * 9 + kk];
+            wr[it] = (o0 + o < p.O && kk < cleft * 9) ? p.w[(size_t)(o0 + o) * C * 9 + (size_t)c0 * 9 + kk] : 0.f;
         }
+    };
+    auto lstore = [&](float (*xs)[XH][CV_XW], float (*ws)[CV_WLD]) {
 #pragma unroll
         for (int it = 0; it < XN; ++it) {
             const int idx = t + it * 256;
-            if (idx < CV_CC * XH * CV_XW) (&Xs[0][0][0])[idx] = xr[it];
+            if (idx < CV_CC * XH * CV_XW) (&xs[0][0][0])[idx] = xr[it];
         }
 #pragma unroll
         for (int it = 0; it < WN; ++it) {
             const int idx = t + it * 256;
             const int o = idx / (CV_CC * 9), kk = idx - o * (CV_CC * 9);
-            Ws[o][kk] = wr[it];
+            ws[o][kk] = wr[it];
         }
-        __syncthreads();
+    };
+    if (c_begin < c_end) { gload(c_begin); lstore(Xs[0], Ws[0]); }
+    __syncthreads();
+    int buf = 0;
+    for (int c0 = c_begin; c0 < c_end; c0 += CV_CC, buf ^= 1) {
+        const bool has_next = c0 + CV_CC < c_end;
+#if !defined(CVF_ABL) || !(CVF_ABL & 1)
+        if (has_next) gload(c0 + CV_CC);
+#endif
         // ---- 36 MFMA k-steps ---------------------------------------------------------------------
 #pragma unroll
         for (int cp = 0; cp < CV_CC / 2; ++cp) {
@@ -115,32 +137,54 @@ __global__ void __launch_bounds__(256) k_conv3x3_f32(ConvP p)
 #pragma unroll
             for (int r = 0; r < RW + 2; ++r)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) xv[r][j] = Xs[ch][r0 + r][l31 + j];
+                for (int j = 0; j < 3; ++j) xv[r][j] = Xs[buf][ch][r0 + r][l31 + j];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
 #pragma unroll
                     for (int ob = 0; ob < OBW; ++ob) {
-                        const float a = Ws[(ob0 + ob) * 32 + l31][ch * 9 + i * 3 + j];
+                        const float a = Ws[buf][(ob0 + ob) * 32 + l31][ch * 9 + i * 3 + j];
 #pragma unroll
                         for (int rr = 0; rr < RW; ++rr)
                             acc[ob][rr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xv[i + rr][j], acc[ob][rr], 0, 0, 0);
                     }
                 }
         }
+        if (has_next) lstore(Xs[buf ^ 1], Ws[buf ^ 1]);
         __syncthreads();
     }
 
     // ---- epilogue -------------------------------------------------------------------------------
     const int gw = w0 + l31;
     if (gw >= W) return;
+#if defined(CVF_ABL) && (CVF_ABL & 2)
+    if (acc[0][0][0] != 12345.f) return;          // timing-only ablation: no epilogue
+#endif
 #pragma unroll
     for (int ob = 0; ob < OBW; ++ob)
 #pragma unroll
         for (int rr = 0; rr < RW; ++rr) {
             const int gh = h0 + r0 + rr;
             if (gh >= H) continue;
+            if (EPI == EPI_PS_SILU && p.s == 2) {
+                // stride-2 PixelShuffle: accumulator registers (reg, reg + 1), reg even, are output channels (o, o + 1) = the two
+                // horizontal sub-pixels sj = 0, 1 of one (n, si): one 8-byte store per lane instead of two 4-byte stores 8 bytes
+                // apart (the scattered form cost 0.5 ms of the 2.3 ms forward at 720p: tools/probes, CVF_ABL)
+                const int Cn = p.O >> 2;
+#pragma unroll
+                for (int reg = 0; reg < 16; reg += 2) {
+                    const int o = o0 + (ob0 + ob) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                    if (o >= p.O) continue;                         // O % 4 == 0: o + 1 exists with o
+                    float v0 = acc[ob][rr][reg], v1 = acc[ob][rr][reg + 1];
+                    if (p.bias) { v0 += p.bias[o]; v1 += p.bias[o + 1]; }
+                    const int n = o >> 2, si = (o >> 1) & 1;
+                    const size_t idx = (((size_t)b * Cn + n) * (H * 2) + (gh * 2 + si)) * (size_t)(W * 2) + (size_t)gw * 2;
+                    if (p.z) *reinterpret_cast<float2 *>(p.z + idx) = make_float2(v0, v1);
+                    *reinterpret_cast<float2 *>(p.out + idx) = make_float2(orn_silu_exact(v0), orn_silu_exact(v1));
+                }
+                continue;
+            }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int o = o0 + (ob0 + ob) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
@@ -292,7 +336,7 @@ struct WgradP {
     int tiles_w, tiles_h, n_ktiles, S, n_ntiles;
 };
 
-__global__ void __launch_bounds__(256) k_wgrad_f32(WgradP p)
+__global__ void __launch_bounds__(256, (F32_MINB > 3 ? 3 : F32_MINB)) k_wgrad_f32(WgradP p)
 {
     __shared__ float Ds[WG_BO][WG_NPX + 1];
     __shared__ float Xs[WG_MAXC][WG_XH][WG_XW];
@@ -323,15 +367,17 @@ __global__ void __launch_bounds__(256) k_wgrad_f32(WgradP p)
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 
     const int tiles_per_img = p.tiles_w * p.tiles_h;
-    for (int kt = blockIdx.y; kt < p.n_ktiles; kt += p.S) {
+    // Round 3: the loads of K tile k+1 are issued into registers before the 128 MFMAs of tile k and stored to LDS behind them
+    // (single LDS buffer, two barriers per tile, no exposed memory latency).
+    constexpr int DN = (WG_BO * WG_NPX) / 256, XN = (WG_MAXC * WG_XH * WG_XW + 255) / 256;
+    float dr[DN], xr[XN];
+    auto gload = [&](const int kt) {
         const int b = kt / tiles_per_img;
         const int rem = kt - b * tiles_per_img;
         const int th = rem / p.tiles_w, tw = rem - th * p.tiles_w;
         const int h0 = th * WG_TH, w0 = tw * WG_TW;
         const float *xb = p.x + (size_t)b * C * H * W;
         const float *dyb = p.dy + (size_t)b * p.O * H * W;
-        constexpr int DN = (WG_BO * WG_NPX) / 256, XN = (WG_MAXC * WG_XH * WG_XW + 255) / 256;
-        float dr[DN], xr[XN];
 #pragma unroll
         for (int it = 0; it < DN; ++it) {
             const int idx = t + it * 256;
@@ -352,6 +398,10 @@ __global__ void __launch_bounds__(256) k_wgrad_f32(WgradP p)
             if (idx < WG_MAXC * WG_XH * WG_XW && gc < C && gh >= 0 && gh < H && gw >= 0 && gw < W)
                 xr[it] = xb[((size_t)gc * H + gh) * W + gw];
         }
+    };
+    if ((int)blockIdx.y < p.n_ktiles) gload(blockIdx.y);
+    for (int kt = blockIdx.y; kt < p.n_ktiles; kt += p.S) {
+        if (kt != (int)blockIdx.y) __syncthreads();        // everyone is done with the previous tile's LDS image
 #pragma unroll
         for (int it = 0; it < DN; ++it) {
             const int idx = t + it * 256;
@@ -364,6 +414,7 @@ __global__ void __launch_bounds__(256) k_wgrad_f32(WgradP p)
             if (idx < WG_MAXC * WG_XH * WG_XW) (&Xs[0][0][0])[idx] = xr[it];
         }
         __syncthreads();
+        if (kt + p.S < p.n_ktiles) gload(kt + p.S);
         const float *dsp = &Ds[0][0] + doff;
         const float *xs0 = &Xs[0][0][0] + xoff[0];
         const float *xs1 = &Xs[0][0][0] + xoff[1];
@@ -377,7 +428,6 @@ __global__ void __launch_bounds__(256) k_wgrad_f32(WgradP p)
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
             }
-        __syncthreads();
     }
 
     float *out = p.partial + (size_t)blockIdx.y * p.O * N;
