@@ -37,6 +37,7 @@ struct ConvP {
     int B, C, O, H, W, s;
     int tiles_w, tiles_h;
     int nsplit, c_per_split;   // EPI_PLAIN: input channels split over blockIdx.z (partial slabs, reduced afterwards)
+    int o_first;               // first output channel of this launch (a ragged O is covered by a second, narrower launch)
 };
 
 // SMALL = 1: 2-row tiles (64 pixels), each wave one 32x32 block -- 4x more work-groups for the small early layers,
@@ -44,22 +45,25 @@ struct ConvP {
 #ifndef F32_MINB
 #define F32_MINB 2          /* two work-groups per CU: <= 256 VGPRs */
 #endif
-template <int EPI, int SMALL>
+// NOB = 32-channel blocks of the work-group's output-channel tile: 2 (64 channels), or 1 for the last 32 channels of an O that is
+// 32 mod 64 (the dgrad of every 96-channel layer: as a second 64-channel tile, half of its MFMA work was thrown away).
+template <int EPI, int SMALL, int NOB = 2>
 __global__ void __launch_bounds__(256, F32_MINB) k_conv3x3_f32(ConvP p)
 {
     constexpr int TH = SMALL ? 2 : CV_TH;
     constexpr int XH = TH + 2;
     constexpr int RW = SMALL ? 1 : 2;          // rows per wave
-    constexpr int OBW = SMALL ? 1 : 2;         // 32-channel blocks per wave
+    constexpr int OBW = SMALL ? 1 : NOB;       // 32-channel blocks per wave
+    constexpr int BO = SMALL ? CV_BO : 32 * NOB;
     __shared__ float Xs[2][CV_CC][XH][CV_XW];
-    __shared__ float Ws[2][CV_BO][CV_WLD];
+    __shared__ float Ws[2][BO][CV_WLD];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     const int tile = blockIdx.x;
     const int tw = tile % p.tiles_w, th = tile / p.tiles_w;
     const int h0 = th * TH, w0 = tw * CV_TW;
-    const int o0 = blockIdx.y * CV_BO;
+    const int o0 = p.o_first + blockIdx.y * BO;
     const int b = blockIdx.z / p.nsplit, split = blockIdx.z - b * p.nsplit;
     const int C = p.C, H = p.H, W = p.W;
     const float *xb = p.x + (size_t)b * C * H * W;
@@ -79,7 +83,7 @@ __global__ void __launch_bounds__(256, F32_MINB) k_conv3x3_f32(ConvP p)
     // of chunk k and stored to the other LDS buffer behind them: one barrier per chunk and no exposed memory latency (the first
     // form staged a chunk, synchronised, computed, synchronised: two work-groups per CU took turns waiting for memory).
     // Per-thread source offsets of the input patch are chunk-invariant (relative to the chunk's first channel) and computed once.
-    constexpr int XN = (CV_CC * XH * CV_XW + 255) / 256, WN = (CV_BO * CV_CC * 9) / 256;
+    constexpr int XN = (CV_CC * XH * CV_XW + 255) / 256, WN = (BO * CV_CC * 9) / 256;
     int xoff[XN];                                      // < 0: zero padding (outside the image / the patch)
 #pragma unroll
     for (int it = 0; it < XN; ++it) {
@@ -230,7 +234,7 @@ int orn_launch_conv3x3_f32(const float *x, const float *w, const float *bias, in
     const bool small = conv_small(B, O, H, W);
     p.tiles_w = orn_cdiv(W, CV_TW);
     p.tiles_h = orn_cdiv(H, small ? 2 : CV_TH);
-    p.nsplit = 1; p.c_per_split = C;
+    p.nsplit = 1; p.c_per_split = C; p.o_first = 0;
     if (epi == EPI_PLAIN && split_ws && !bias) {
         const int ns = orn_conv3x3_f32_nsplit(B, C, O, H, W);
         if (ns > 1) {
@@ -244,6 +248,17 @@ int orn_launch_conv3x3_f32(const float *x, const float *w, const float *bias, in
             const size_t n = (size_t)B * O * H * W;
             return orn_launch_reduce_rows(split_ws, p.nsplit, n, n, out, st);
         }
+    }
+    if (!small && epi == EPI_PLAIN && O % CV_BO == 32) {
+        // whole 64-channel tiles, then the last 32 channels on a 32-channel tile
+        if (O >= CV_BO) {
+            hipLaunchKernelGGL((k_conv3x3_f32<EPI_PLAIN, 0, 2>), dim3(p.tiles_w * p.tiles_h, O / CV_BO, B), dim3(256), 0, st, p);
+            ORN_LAUNCH_CHECK("conv3x3_f32");
+        }
+        p.o_first = O / CV_BO * CV_BO;
+        hipLaunchKernelGGL((k_conv3x3_f32<EPI_PLAIN, 0, 1>), dim3(p.tiles_w * p.tiles_h, 1, B), dim3(256), 0, st, p);
+        ORN_LAUNCH_CHECK("conv3x3_f32(32)");
+        return 0;
     }
     dim3 grid(p.tiles_w * p.tiles_h, orn_cdiv(O, CV_BO), B);
     if (epi == EPI_PS_SILU) {
