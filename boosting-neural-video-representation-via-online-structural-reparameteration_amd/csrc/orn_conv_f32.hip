@@ -348,7 +348,7 @@ struct WgradP {
     const float *dy;   // [B,O,H,W]
     float *partial;    // [S][O][C*9]
     int B, C, O, H, W;
-    int tiles_w, tiles_h, n_ktiles, S, n_ntiles;
+    int tiles_w, tiles_h, n_ktiles, S, n_ntiles, n_otiles, n_items, items_per_xcd;
 };
 
 __global__ void __launch_bounds__(256, (F32_MINB > 3 ? 3 : F32_MINB)) k_wgrad_f32(WgradP p)
@@ -358,7 +358,15 @@ __global__ void __launch_bounds__(256, (F32_MINB > 3 ? 3 : F32_MINB)) k_wgrad_f3
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
-    const int ot = blockIdx.x / p.n_ntiles, nt = blockIdx.x - ot * p.n_ntiles;
+    // XCD-aware decode (work-groups go round the 8 XCDs, each with its own L2): every XCD takes a contiguous range of the
+    // (split, o tile, n tile) items with the n tile fastest, so the n tiles that share one dy tile -- and, next, the o tiles that
+    // share one x patch -- run on one L2 instead of each fetching it from beyond.
+    const int per_xcd = p.items_per_xcd;
+    const int item = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (((int)blockIdx.x >> 3) >= per_xcd || item >= p.n_items) return;
+    const int n_on = p.n_otiles * p.n_ntiles;
+    const int ksplit = item / n_on, on = item - ksplit * n_on;
+    const int ot = on / p.n_ntiles, nt = on - ot * p.n_ntiles;
     const int o0 = ot * WG_BO, n0 = nt * WG_BN;
     const int C = p.C, H = p.H, W = p.W, N = C * 9;
     const int c_lo = n0 / 9;
@@ -386,6 +394,20 @@ __global__ void __launch_bounds__(256, (F32_MINB > 3 ? 3 : F32_MINB)) k_wgrad_f3
     // (single LDS buffer, two barriers per tile, no exposed memory latency).
     constexpr int DN = (WG_BO * WG_NPX) / 256, XN = (WG_MAXC * WG_XH * WG_XW + 255) / 256;
     float dr[DN], xr[XN];
+    // Index arithmetic of the 45 staging loads, hoisted (it cost ~700 vector instructions per K tile, a third of the 128 MFMAs'
+    // issue time): dy element idx = t + 256 it is (o = (t >> 7) + 2 it, pixel t & 127), i.e. a per-thread base + it * 2 H W; the
+    // x patch offsets (relative to the tile origin) are tile-invariant.  Tiles that touch the image border keep the general form.
+    const int dr_r = (t >> 5) & 3, dr_x = t & 31, dr_o = t >> 7;
+    int xo[XN];                                           // x patch element -> offset from (channel c_lo, row h0, col w0); INT_MIN: not a patch element / no such channel
+#pragma unroll
+    for (int it = 0; it < XN; ++it) {
+        const int idx = t + it * 256;
+        const int c = idx / (WG_XH * WG_XW);
+        const int rem2 = idx - c * (WG_XH * WG_XW);
+        const int r = rem2 / WG_XW, xx = rem2 - r * WG_XW;
+        xo[it] = (idx < WG_MAXC * WG_XH * WG_XW && c_lo + c < C) ? (c * H + r - 1) * W + xx - 1 : INT_MIN;       // (-1 is a real offset: c 0, r 1, xx 0)
+    }
+    const bool o_full = o0 + WG_BO <= p.O;
     auto gload = [&](const int kt) {
         const int b = kt / tiles_per_img;
         const int rem = kt - b * tiles_per_img;
@@ -393,6 +415,16 @@ __global__ void __launch_bounds__(256, (F32_MINB > 3 ? 3 : F32_MINB)) k_wgrad_f3
         const int h0 = th * WG_TH, w0 = tw * WG_TW;
         const float *xb = p.x + (size_t)b * C * H * W;
         const float *dyb = p.dy + (size_t)b * p.O * H * W;
+        if (o_full && h0 >= 1 && h0 + WG_TH + 1 <= H && w0 >= 1 && w0 + WG_TW + 1 <= W) {      // interior tile (wave-uniform)
+            const float *dp = dyb + ((size_t)(o0 + dr_o) * H + h0 + dr_r) * W + w0 + dr_x;
+            const size_t ostep = (size_t)2 * H * W;
+#pragma unroll
+            for (int it = 0; it < DN; ++it) dr[it] = dp[(size_t)it * ostep];
+            const float *xp = xb + ((size_t)c_lo * H + h0) * W + w0;
+#pragma unroll
+            for (int it = 0; it < XN; ++it) xr[it] = xo[it] != INT_MIN ? xp[xo[it]] : 0.f;
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < DN; ++it) {
             const int idx = t + it * 256;
@@ -414,9 +446,9 @@ __global__ void __launch_bounds__(256, (F32_MINB > 3 ? 3 : F32_MINB)) k_wgrad_f3
                 xr[it] = xb[((size_t)gc * H + gh) * W + gw];
         }
     };
-    if ((int)blockIdx.y < p.n_ktiles) gload(blockIdx.y);
-    for (int kt = blockIdx.y; kt < p.n_ktiles; kt += p.S) {
-        if (kt != (int)blockIdx.y) __syncthreads();        // everyone is done with the previous tile's LDS image
+    if (ksplit < p.n_ktiles) gload(ksplit);
+    for (int kt = ksplit; kt < p.n_ktiles; kt += p.S) {
+        if (kt != ksplit) __syncthreads();        // everyone is done with the previous tile's LDS image
 #pragma unroll
         for (int it = 0; it < DN; ++it) {
             const int idx = t + it * 256;
@@ -445,7 +477,7 @@ __global__ void __launch_bounds__(256, (F32_MINB > 3 ? 3 : F32_MINB)) k_wgrad_f3
             }
     }
 
-    float *out = p.partial + (size_t)blockIdx.y * p.O * N;
+    float *out = p.partial + (size_t)ksplit * p.O * N;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int n = n0 + (2 * wn + q) * 32 + l31;
@@ -504,7 +536,10 @@ int orn_launch_conv_bwd_f32(const float *x, const float *wf, const float *z, con
     p.n_ktiles = B * p.tiles_w * p.tiles_h;
     p.S = S;
     p.n_ntiles = orn_cdiv(C * 9, WG_BN);
-    hipLaunchKernelGGL(k_wgrad_f32, dim3(orn_cdiv(O, WG_BO) * p.n_ntiles, S), dim3(256), 0, st, p);
+    p.n_otiles = orn_cdiv(O, WG_BO);
+    p.n_items = p.n_otiles * p.n_ntiles * S;
+    p.items_per_xcd = orn_cdiv(p.n_items, 8);
+    hipLaunchKernelGGL(k_wgrad_f32, dim3(p.items_per_xcd * 8), dim3(256), 0, st, p);
     ORN_LAUNCH_CHECK("wgrad_f32");
     ORN_TRY(orn_launch_reduce_rows(slabs, S, (size_t)O * C * 9, (size_t)O * C * 9, dwf, st));
 
