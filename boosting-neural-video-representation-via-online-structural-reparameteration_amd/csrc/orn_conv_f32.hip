@@ -8,7 +8,7 @@
 //
 // Lane maps (MI355X guide): A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D col = l&31,
 // row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
-#include "orn_common.h"
+#include "orn_internal.h"
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -514,7 +514,8 @@ extern "C" size_t orn_conv3x3_ps_silu_bwd_ws_bytes(int B, int C, int O, int H, i
 }
 
 int orn_launch_conv_bwd_f32(const float *x, const float *wf, const float *z, const float *da, int B, int C, int O,
-                            int H, int W, int s, float *dx, float *dwf, float *dbf, float *ws, hipStream_t st)
+                            int H, int W, int s, float *dx, float *dwf, float *dbf, float *ws, hipStream_t st,
+                            const OrnHeadBwdFuse *head)
 {
     const size_t HW = (size_t)H * W;
     const int chunks = orn_cdiv((long)HW, DY_PPB);
@@ -525,8 +526,16 @@ int orn_launch_conv_bwd_f32(const float *x, const float *wf, const float *z, con
     float *dbp = slabs + orn_align((size_t)S * O * C * 9 * 4) / 4;
     float *dgs = dbp + orn_align((size_t)B * chunks * O * 4) / 4;
 
-    hipLaunchKernelGGL(k_silu_bwd_unshuffle, dim3(chunks, O, B), dim3(256), 0, st, da, z, O, H, W, s, dy, dbp);
-    ORN_LAUNCH_CHECK("silu_bwd_unshuffle");
+    if (head) {
+        // the last block of the fp32 engine: head backward, SiLU' and the un-shuffle in one pass (dy and the dbias partials land where
+        // k_silu_bwd_unshuffle would have put them; its blocks cover the same DY_PPB pixels)
+        ORN_REQUIRE(B == 1 && s == 2 && orn_head_bwd_fused_f32_blocks(H, W) == chunks, "conv_bwd_f32: fused head backward needs B == 1, s == 2");
+        ORN_TRY(orn_launch_head_bwd_fused_f32(z, head->w, head->out, head->dout, O / 4, H, W, head->sigmoid, dy, dbp, head->dw, head->db,
+                                              head->hws, st));
+    } else {
+        hipLaunchKernelGGL(k_silu_bwd_unshuffle, dim3(chunks, O, B), dim3(256), 0, st, da, z, O, H, W, s, dy, dbp);
+        ORN_LAUNCH_CHECK("silu_bwd_unshuffle");
+    }
     ORN_TRY(orn_launch_reduce_rows(dbp, B * chunks, (size_t)O, (size_t)O, dbf, st));
 
     WgradP p;

@@ -486,6 +486,125 @@ int orn_launch_head_bwd(const float *a, const float *w, const float *out, const 
     return 0;
 }
 
+// fp32 engine, last block with a stride-2 PixelShuffle: head backward + SiLU' + un-shuffle in ONE pass over z.
+//   du = dout * act'(out);  a = SiLU(z) (recomputed: bit-identical to the forward's);  dz = (W^T du) * SiLU'(z)
+//   dy[o = 4 n + 2 si + sj][h][w] = dz[n][2 h + si][2 w + sj];  head dW[k][n] += du[k] a;  head db[k] += du[k];  conv dbias[o] += dy
+// The unfused pair (k_head_bwd: read a, write da; k_silu_bwd_unshuffle: read da and z, write dy) moved 5 activation-sized
+// tensors through HBM (1.77 GB at 720p, 750 us); this one moves 2 (z in, dy out).
+// Block = 512 threads x 4 low-res pixels (= the 2048 pixels of one dbias-partial chunk of orn_conv_f32.hip); partials in fixed order.
+#define HF_PPT 4
+#define HF_THREADS 512
+__global__ void __launch_bounds__(HF_THREADS)
+k_head_bwd_fused_f32(const float *__restrict__ z, const float *__restrict__ w, const float *__restrict__ out,
+                     const float *__restrict__ dout, int Cn, int H, int W, int sigmoid, float *__restrict__ dy,
+                     float *__restrict__ dbp, float *__restrict__ hpart)
+{
+    extern __shared__ float hf_smem[];
+    float *sw = hf_smem;                              // [3 Cn]
+    float *sred = hf_smem + 3 * Cn;                   // [8 waves][7 Cn + 3]: head dW (3 Cn), conv dbias (4 Cn), head db (3)
+    const int nred = 7 * Cn + 3;
+    for (int i = threadIdx.x; i < 3 * Cn; i += HF_THREADS) sw[i] = w[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Ws = 2 * W;
+    const size_t HW = (size_t)H * W, HWs = 4 * HW;
+    float du[3][HF_PPT][4];
+    int zoff[HF_PPT];                                 // offset of (2h, 2w) in a high-res plane; < 0: no such pixel
+    unsigned pix[HF_PPT];
+#pragma unroll
+    for (int i = 0; i < HF_PPT; ++i) {
+        const size_t pp = (size_t)blockIdx.x * (HF_THREADS * HF_PPT) + (size_t)i * HF_THREADS + threadIdx.x;
+        const bool ok = pp < HW;
+        const int h = ok ? (int)(pp / W) : 0, ww = ok ? (int)(pp - (size_t)h * W) : 0;
+        zoff[i] = ok ? (2 * h) * Ws + 2 * ww : -1;
+        pix[i] = (unsigned)pp;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int si = 0; si < 2; ++si) {
+                float2 o = make_float2(0.f, 0.f), g = make_float2(0.f, 0.f);
+                if (ok) {
+                    o = *reinterpret_cast<const float2 *>(out + (size_t)k * HWs + zoff[i] + si * Ws);
+                    g = *reinterpret_cast<const float2 *>(dout + (size_t)k * HWs + zoff[i] + si * Ws);
+                }
+                // o = (tanh u + 1)/2 -> do/du = 2 o (1-o);  sigmoid: o (1-o)
+                du[k][i][2 * si + 0] = g.x * (sigmoid ? o.x * (1.0f - o.x) : 2.0f * o.x * (1.0f - o.x));
+                du[k][i][2 * si + 1] = g.y * (sigmoid ? o.y * (1.0f - o.y) : 2.0f * o.y * (1.0f - o.y));
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float sdu = 0.f;
+#pragma unroll
+        for (int i = 0; i < HF_PPT; ++i) sdu += (du[k][i][0] + du[k][i][1]) + (du[k][i][2] + du[k][i][3]);
+        sdu = orn_wave_sum(sdu);
+        if (lane == 0) sred[wave * nred + 7 * Cn + k] = sdu;
+    }
+    for (int n = 0; n < Cn; ++n) {
+        const float w0 = sw[n], w1 = sw[Cn + n], w2 = sw[2 * Cn + n];
+        const float *zn = z + (size_t)n * HWs;
+        float2 zv[HF_PPT][2];
+#pragma unroll
+        for (int i = 0; i < HF_PPT; ++i)
+#pragma unroll
+            for (int si = 0; si < 2; ++si)
+                zv[i][si] = zoff[i] >= 0 ? *reinterpret_cast<const float2 *>(zn + zoff[i] + si * Ws) : make_float2(0.f, 0.f);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, db4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < HF_PPT; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float zz = (q & 1) ? zv[i][q >> 1].y : zv[i][q >> 1].x;
+                const float sg = 1.0f / (1.0f + expf(-zz));
+                const float a = zz * sg;                                           // (== orn_silu_exact up to the division's rounding: see the test tolerance)
+                const float da = fmaf(w2, du[2][i][q], fmaf(w1, du[1][i][q], w0 * du[0][i][q]));
+                const float dz = da * (sg * (1.0f + zz * (1.0f - sg)));             // orn_silu_grad_exact
+                s0 = fmaf(du[0][i][q], a, s0);
+                s1 = fmaf(du[1][i][q], a, s1);
+                s2 = fmaf(du[2][i][q], a, s2);
+                db4[q] += dz;
+                if (zoff[i] >= 0) dy[((size_t)n * 4 + q) * HW + pix[i]] = dz;
+            }
+        s0 = orn_wave_sum(s0); s1 = orn_wave_sum(s1); s2 = orn_wave_sum(s2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) db4[q] = orn_wave_sum(db4[q]);
+        if (lane == 0) {
+            float *r = sred + wave * nred;
+            r[n] = s0; r[Cn + n] = s1; r[2 * Cn + n] = s2;
+            r[3 * Cn + 4 * n + 0] = db4[0]; r[3 * Cn + 4 * n + 1] = db4[1]; r[3 * Cn + 4 * n + 2] = db4[2]; r[3 * Cn + 4 * n + 3] = db4[3];
+        }
+    }
+    __syncthreads();
+    const int O = 4 * Cn;
+    for (int i = threadIdx.x; i < nred; i += HF_THREADS) {
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < HF_THREADS / 64; ++wv) v += sred[wv * nred + i];
+        if (i < 3 * Cn) hpart[(size_t)blockIdx.x * (3 * Cn + 3) + i] = v;
+        else if (i < 7 * Cn) dbp[(size_t)blockIdx.x * O + (i - 3 * Cn)] = v;
+        else hpart[(size_t)blockIdx.x * (3 * Cn + 3) + 3 * Cn + (i - 7 * Cn)] = v;
+    }
+}
+
+int orn_head_bwd_fused_f32_blocks(int H, int W) { return orn_cdiv((long)H * W, HF_THREADS * HF_PPT); }
+
+// dy [4 Cn][H][W] and dbp [blocks][4 Cn] belong to the caller (the conv backward's workspace); hws: (blocks + 1) x (3 Cn + 3) floats
+int orn_launch_head_bwd_fused_f32(const float *z, const float *w, const float *out, const float *dout, int Cn, int H, int W,
+                                  int sigmoid, float *dy, float *dbp, float *dw, float *db, float *hws, hipStream_t st)
+{
+    ORN_REQUIRE(Cn <= ORN_HEAD_MAXC, "head: C=%d > %d unsupported", Cn, ORN_HEAD_MAXC);
+    const int nblk = orn_head_bwd_fused_f32_blocks(H, W);
+    const size_t n = 3 * (size_t)Cn + 3;
+    const size_t lds = ((size_t)3 * Cn + (size_t)(HF_THREADS / 64) * (7 * Cn + 3)) * sizeof(float);
+    float *partial = hws, *red = hws + (size_t)nblk * n;
+    hipLaunchKernelGGL(k_head_bwd_fused_f32, dim3(nblk), dim3(HF_THREADS), lds, st, z, w, out, dout, Cn, H, W, sigmoid, dy, dbp, partial);
+    ORN_LAUNCH_CHECK("head_bwd_fused_f32");
+    ORN_TRY(orn_launch_reduce_rows(partial, nblk, n, n, red, st));
+    hipLaunchKernelGGL(k_head_split_dw, dim3(orn_cdiv((long)n, 128)), dim3(128), 0, st, red, Cn, dw, db);
+    ORN_LAUNCH_CHECK("head_split");
+    return 0;
+}
+
 extern "C" int orn_head_bwd(const float *a, const float *w, const float *out, const float *dout, int B, int C, int H,
                             int W, int sigmoid, float *da, float *dw, float *db, void *ws, size_t ws_bytes,
                             void *stream)

@@ -177,7 +177,10 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
     const size_t s3 = (ff < d->n_layers) ? orn_half_ops_bf16()->head_bwd_ws_floats(Cn) : orn_head_bwd_ws_bytes(1, Cn, H, W) / 4;
     if (s3 > scratch) scratch = s3;
     float *scr = take(scratch);
-    float *head_ws = (ff < d->n_layers) ? take(orn_half_ops_bf16()->head_bwd_ws_floats(Cn)) : nullptr;
+    // (fp32 engine: partials of the fused head backward of the last block, stride 2 only)
+    const orn_layer_desc &ll = d->layer[d->n_layers - 1];
+    float *head_ws = (ff < d->n_layers) ? take(orn_half_ops_bf16()->head_bwd_ws_floats(Cn))
+                   : (ll.s == 2 ? take((size_t)(orn_head_bwd_fused_f32_blocks(ll.H, ll.W) + 1) * (3 * Cn + 3)) : nullptr);
     float *cur = take((sizeof(OrnStepCur) * ORN_GRAPH_UNROLL + 3) / 4 + 16);    // one cursor state per step of the unrolled graph
     float *scs = take(sizeof(OrnScaleState) / 4);
     float *mtab = d->erb ? take(orn_merge_group_bytes() / 4) : nullptr;
@@ -508,7 +511,10 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
     if (ff < nl)
         ORN_TRY(e->ops->head_bwd(e->L[nl - 1].zb, P + d.head_w, e->img, e->dimg, e->Cn_last, e->Hout, e->Wout, d.sigmoid,
                                  d.layer[nl - 1].s, e->gs, e->L[nl - 1].dypad, nullptr, nullptr, e->head_ws, st, e->sc, &fin));   // dW / db: finished with the wgrad batch
-    else
+    static const bool no_head_fuse = getenv("ORN_F32_HEAD_UNFUSED") != nullptr;       // tools/probes A/B
+    const bool head_fused32 = ff >= nl && e->head_ws && d.layer[nl - 1].s == 2 && !no_head_fuse;
+    const OrnHeadBwdFuse hfuse = {P + d.head_w, e->img, e->dimg, d.sigmoid, G + d.head_w, G + d.head_b, e->head_ws};
+    if (ff >= nl && !head_fused32)
         ORN_TRY(orn_launch_head_bwd(e->L[nl - 1].a, P + d.head_w, e->img, e->dimg, 1, e->Cn_last, HWo, d.sigmoid, e->L[nl - 1].da,
                                     G + d.head_w, G + d.head_b, e->scratch, st));
     int wgrad_rode[ORN_MAX_LAYERS] = {};
@@ -539,7 +545,8 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
             ORN_TRY(orn_launch_stage0_bwd(x, b.wf, b.z, e->dxn, e->ops->dgrad_f32_slabs(l1.H, l1.W, l1.O), ORN_FAST_C, 1.0f / e->gs, l.C, l.O,
                                           l.H, l.W, l.s, e->scratch + e->stem_ws, nullptr, G + l.w3x3, G + l.b3x3, st, e->sc));
         } else
-        ORN_TRY(orn_launch_conv_bwd_f32(x, b.wf, b.z, b.da, 1, l.C, l.O, l.H, l.W, l.s, dx, G + l.w3x3, G + l.b3x3, e->scratch, st));
+        ORN_TRY(orn_launch_conv_bwd_f32(x, b.wf, b.z, b.da, 1, l.C, l.O, l.H, l.W, l.s, dx, G + l.w3x3, G + l.b3x3, e->scratch, st,
+                                        (i == nl - 1 && head_fused32) ? &hfuse : nullptr));
         if (e->prof) (void)hipEventRecord(e->prof_ev[2 * ORN_MAX_LAYERS + 2 * i + 1], st);
     }
     // stem backward; with a wgrad batch behind it, its last kernel (needed by Adam only) rides along that launch

@@ -88,8 +88,14 @@ int orn_launch_merge_bwd_tail_all(int n, const OrnMergeMisc *L, hipStream_t st);
 // orn_conv_f32.hip
 int orn_launch_conv3x3_f32(const float *x, const float *w, const float *bias, int B, int C, int O, int H, int W,
                            int s, int epi, float *z, float *out, hipStream_t st, float *split_ws);
+// head: fp32 engine only -- the last block's backward starts from the head's (out, dout) instead of da (orn_launch_head_bwd_fused_f32)
+struct OrnHeadBwdFuse { const float *w, *out, *dout; int sigmoid; float *dw, *db, *hws; };
 int orn_launch_conv_bwd_f32(const float *x, const float *wf, const float *z, const float *da, int B, int C, int O,
-                            int H, int W, int s, float *dx, float *dwf, float *dbf, float *ws, hipStream_t st);
+                            int H, int W, int s, float *dx, float *dwf, float *dbf, float *ws, hipStream_t st,
+                            const OrnHeadBwdFuse *head = nullptr);
+int orn_head_bwd_fused_f32_blocks(int H, int W);
+int orn_launch_head_bwd_fused_f32(const float *z, const float *w, const float *out, const float *dout, int Cn, int H, int W,
+                                  int sigmoid, float *dy, float *dbp, float *dw, float *db, float *hws, hipStream_t st);
 
 // orn_loss.hip
 int orn_loss_init();
