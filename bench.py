@@ -439,12 +439,18 @@ def launch(args):
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    import tempfile
+    logdir = tempfile.mkdtemp(prefix='orn_bench_ranks_')
+    procs, logs = [], []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                    ORN_BENCH_CHILD='1')
+        # ranks >= 1 print nothing on stdout in a good run; what they do print (and their stderr) goes to a per-rank log that is
+        # shown when the run fails, instead of being thrown away
+        log = None if r == 0 else open(os.path.join(logdir, f'rank{r}.log'), 'w')
+        logs.append(log)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=(subprocess.PIPE if r == 0 else subprocess.DEVNULL), text=True))
+                                      stdout=(subprocess.PIPE if r == 0 else log), stderr=(None if r == 0 else subprocess.STDOUT), text=True))
     # rank 0's line is read by a thread; the ranks are polled so that one dying rank ends the run (its peers would wait in
     # the rendezvous or a barrier forever): the children this process started are then terminated by PID
     import threading
@@ -469,6 +475,12 @@ def launch(args):
             except subprocess.TimeoutExpired:
                 p.kill()
         sys.stderr.write(f'bench.py: rank {failed} failed (exit codes {[p.returncode for p in procs]})\n')
+        for r, log in enumerate(logs):
+            if log is not None:
+                log.close()
+                tail = open(log.name).read()[-2000:]
+                if tail.strip():
+                    sys.stderr.write(f'--- rank {r} output (tail of {log.name}) ---\n{tail}\n')
         raise SystemExit(1)
     th.join(timeout=10)
     sys.stdout.write(buf[0] if buf else '')
