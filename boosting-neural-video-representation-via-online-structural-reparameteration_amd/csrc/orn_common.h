@@ -141,14 +141,18 @@ __device__ __forceinline__ float orn_block_sum(float v, float *smem /* >= 16 flo
 // arena raises `flag`; Adam then leaves parameters and moments untouched (the step is skipped, as torch.cuda.amp.GradScaler
 // does) and the next schedule advance halves the scale.  After ORN_SCALE_GROWTH_INTERVAL clean steps it doubles again, up
 // to its initial value.
+// The engine keeps ORN_SCALE_SLOTS of these, one per step of its unrolled graph: the kernels of step r read the scale from and
+// raise the flag of entry r, so an overflowing step skips ITSELF only; entry 0 is also the master record (skipped, good,
+// backoffs, gs_max, launched), and k_advance folds the flags into the scale and copies it to every entry.
+#define ORN_SCALE_SLOTS 4
 struct OrnScaleState {
     float gs, inv_gs;      // scale carried by the 16-bit gradient tensors, and its reciprocal
     float gs_max;          // initial value: the scale never grows beyond it
-    int32_t flag;          // a non-finite gradient was seen since the last advance
-    int32_t skipped;       // optimiser steps skipped so far (Adam's bias corrections do not count them)
-    int32_t good;          // clean steps since the last change of scale
-    int32_t backoffs;      // times the scale was halved
-    int32_t pad;
+    int32_t flag;          // a non-finite loss or gradient was seen in this entry's step since the last advance
+    int32_t skipped;       // (entry 0) optimiser steps skipped so far (Adam's bias corrections do not count them)
+    int32_t good;          // (entry 0) clean steps since the last change of scale, credited once they have run
+    int32_t backoffs;      // (entry 0) times the scale was halved
+    int32_t launched;      // (entry 0) steps of the group launched at the last advance
 };
 #define ORN_SCALE_GROWTH_INTERVAL 2000
 __device__ __forceinline__ void orn_flag_nonfinite(OrnScaleState *sc, float v)

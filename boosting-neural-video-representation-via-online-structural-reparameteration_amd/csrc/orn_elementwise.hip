@@ -629,11 +629,11 @@ template <bool MASK>
 __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
                        size_t n, float step_size_v, float sqrt_bc2_v, const OrnStepCur *__restrict__ sp, float beta1,
                        float omb1, float beta2, float omb2, float eps, float inv_gscale, const float *__restrict__ gmask,
-                       OrnScaleState *sc)
+                       OrnScaleState *sc, OrnScaleState *sc_master)
 {
     // non-finite gradients somewhere in this step: leave parameters and moments alone (the whole step is skipped)
     if (sc && sc->flag) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) sc->skipped += 1;
+        if (blockIdx.x == 0 && threadIdx.x == 0) sc_master->skipped += 1;
         return;
     }
     // gmask (optional, 0/1 per parameter): the gradient is multiplied by it -- the prune fine-tune of main_eval.py,
@@ -672,16 +672,17 @@ __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float
 }
 
 int orn_launch_adam(float *p, const float *g, float *m, float *v, size_t n, double lr, int step, const OrnStepCur *sp,
-                    double beta1, double beta2, double eps, float inv_gscale, hipStream_t st, const float *gmask, OrnScaleState *sc)
+                    double beta1, double beta2, double eps, float inv_gscale, hipStream_t st, const float *gmask, OrnScaleState *sc,
+                    OrnScaleState *sc_master)
 {
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     const dim3 gr(orn_cdiv((long)orn_cdiv((long)n, 4), 256));
     if (gmask)
         hipLaunchKernelGGL(k_adam<true>, gr, dim3(256), 0, st, p, g, m, v, n, (float)(lr / bc1), (float)sqrt(bc2), sp, (float)beta1,
-                           (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, inv_gscale, gmask, sc);
+                           (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, inv_gscale, gmask, sc, sc_master ? sc_master : sc);
     else
         hipLaunchKernelGGL(k_adam<false>, gr, dim3(256), 0, st, p, g, m, v, n, (float)(lr / bc1), (float)sqrt(bc2), sp, (float)beta1,
-                           (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, inv_gscale, gmask, sc);
+                           (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, inv_gscale, gmask, sc, sc_master ? sc_master : sc);
     ORN_LAUNCH_CHECK("adam");
     return 0;
 }

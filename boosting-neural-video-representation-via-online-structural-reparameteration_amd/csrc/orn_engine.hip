@@ -63,6 +63,7 @@ struct orn_engine {
 };
 
 #define ORN_GRAPH_UNROLL 4
+static_assert(ORN_SCALE_SLOTS >= ORN_GRAPH_UNROLL, "one scale-state entry per step of the unrolled graph");
 
 static inline size_t al(size_t floats) { return orn_align(floats * 4) / 4; }
 
@@ -182,7 +183,7 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
     float *head_ws = (ff < d->n_layers) ? take(orn_half_ops_bf16()->head_bwd_ws_floats(Cn))
                    : (ll.s == 2 ? take((size_t)(orn_head_bwd_fused_f32_blocks(ll.H, ll.W) + 1) * (3 * Cn + 3)) : nullptr);
     float *cur = take((sizeof(OrnStepCur) * ORN_GRAPH_UNROLL + 3) / 4 + 16);    // one cursor state per step of the unrolled graph
-    float *scs = take(sizeof(OrnScaleState) / 4);
+    float *scs = take(sizeof(OrnScaleState) * ORN_SCALE_SLOTS / 4);     // one entry per step of the unrolled graph (entry 0 = master)
     float *mtab = d->erb ? take(orn_merge_group_bytes() / 4) : nullptr;
     float *mhtab = (d->erb && d->precision != 0) ? take(orn_merge_h16_table_bytes() / 4) : nullptr;
     if (e) {
@@ -239,9 +240,9 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
         hipError_t rc = hipMemset(ws, 0, need);
         if (rc == hipSuccess) rc = hipDeviceSynchronize();
         if (rc != hipSuccess) { orn_set_error("engine_create: hipMemset failed: %s", hipGetErrorString(rc)); delete e; return (int)rc; }
-        OrnScaleState s0 = {};
-        s0.gs = e->gs; s0.inv_gs = 1.0f / e->gs; s0.gs_max = e->gs;
-        rc = hipMemcpy(e->sc, &s0, sizeof(s0), hipMemcpyHostToDevice);
+        OrnScaleState s0[ORN_SCALE_SLOTS] = {};
+        for (int r = 0; r < ORN_SCALE_SLOTS; ++r) { s0[r].gs = e->gs; s0[r].inv_gs = 1.0f / e->gs; s0[r].gs_max = e->gs; }
+        rc = hipMemcpy(e->sc, s0, sizeof(s0), hipMemcpyHostToDevice);
         if (rc != hipSuccess) { orn_set_error("engine_create: scale state upload failed: %s", hipGetErrorString(rc)); delete e; return (int)rc; }
     }
     if (!d->erb)
@@ -330,11 +331,14 @@ extern "C" int orn_engine_set_target_stats(orn_engine *e, const float *stats)
 extern "C" int orn_engine_scale_state(orn_engine *e, float *out8)
 {
     ORN_REQUIRE(e && out8, "engine_scale_state: null pointer");
-    OrnScaleState s;
+    OrnScaleState sa[ORN_SCALE_SLOTS];
     hipError_t rc = hipDeviceSynchronize();
-    if (rc == hipSuccess) rc = hipMemcpy(&s, e->sc, sizeof(s), hipMemcpyDeviceToHost);
+    if (rc == hipSuccess) rc = hipMemcpy(sa, e->sc, sizeof(sa), hipMemcpyDeviceToHost);
     if (rc != hipSuccess) { orn_set_error("engine_scale_state: %s", hipGetErrorString(rc)); return (int)rc; }
-    out8[0] = s.gs; out8[1] = s.inv_gs; out8[2] = s.gs_max; out8[3] = (float)s.flag; out8[4] = (float)s.skipped;
+    const OrnScaleState &s = sa[0];
+    int any = 0;                                      // flag: a step since the last advance met a non-finite value
+    for (int r = 0; r < ORN_SCALE_SLOTS; ++r) any |= sa[r].flag;
+    out8[0] = s.gs; out8[1] = s.inv_gs; out8[2] = s.gs_max; out8[3] = (float)any; out8[4] = (float)s.skipped;
     out8[5] = (float)s.good; out8[6] = (float)s.backoffs; out8[7] = 0.f;
     return 0;
 }
@@ -344,12 +348,15 @@ extern "C" int orn_engine_scale_state(orn_engine *e, float *out8)
 extern "C" int orn_engine_set_grad_scale(orn_engine *e, float gs, float gs_max)
 {
     ORN_REQUIRE(e && gs >= 1.0f, "engine_set_grad_scale: scale must be >= 1");
-    OrnScaleState s;
+    OrnScaleState sa[ORN_SCALE_SLOTS];
     hipError_t rc = hipDeviceSynchronize();
-    if (rc == hipSuccess) rc = hipMemcpy(&s, e->sc, sizeof(s), hipMemcpyDeviceToHost);
-    s.gs = gs; s.inv_gs = 1.0f / gs; s.good = 0;
-    if (gs_max > 0.f) s.gs_max = gs_max;
-    if (rc == hipSuccess) rc = hipMemcpy(e->sc, &s, sizeof(s), hipMemcpyHostToDevice);
+    if (rc == hipSuccess) rc = hipMemcpy(sa, e->sc, sizeof(sa), hipMemcpyDeviceToHost);
+    for (int r = 0; r < ORN_SCALE_SLOTS; ++r) {
+        sa[r].gs = gs; sa[r].inv_gs = 1.0f / gs;
+        if (gs_max > 0.f) sa[r].gs_max = gs_max;
+    }
+    sa[0].good = 0;
+    if (rc == hipSuccess) rc = hipMemcpy(e->sc, sa, sizeof(sa), hipMemcpyHostToDevice);
     if (rc != hipSuccess) { orn_set_error("engine_set_grad_scale: %s", hipGetErrorString(rc)); return (int)rc; }
     return 0;
 }
@@ -370,17 +377,21 @@ __global__ void k_advance(const orn_step_sched *__restrict__ sched, int32_t *cur
     const int32_t c0 = *cursor;
     __shared__ int32_t skipped;
     if (threadIdx.x == 0) {
-        // dynamic loss scale: the steps since the last advance met a non-finite gradient (Adam skipped them) -> halve the
-        // scale; ORN_SCALE_GROWTH_INTERVAL clean steps -> double it again, up to its initial value
+        // the steps of the group that has just run: any overflow halves the scale (once per advance); clean groups are credited
+        // now that they HAVE run, and ORN_SCALE_GROWTH_INTERVAL clean steps double the scale again, up to its initial value
+        int nflag = 0;
+        for (int r = 0; r < ORN_SCALE_SLOTS; ++r)
+            if (sc[r].flag) { nflag += 1; sc[r].flag = 0; }
         float gs = sc->gs;
-        if (sc->flag) {
+        if (nflag) {
             gs = fmaxf(gs * 0.5f, 1.0f);
-            sc->flag = 0; sc->good = 0; sc->backoffs += 1;
+            sc->good = 0; sc->backoffs += 1;
         } else {
-            sc->good += count;
+            sc->good += sc->launched;
             if (sc->good >= ORN_SCALE_GROWTH_INTERVAL && gs < sc->gs_max) { gs *= 2.0f; sc->good = 0; }
         }
-        sc->gs = gs; sc->inv_gs = 1.0f / gs;
+        sc->launched = count;
+        for (int r = 0; r < ORN_SCALE_SLOTS; ++r) { sc[r].gs = gs; sc[r].inv_gs = 1.0f / gs; }
         skipped = sc->skipped;
     }
     __syncthreads();
@@ -498,19 +509,20 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
     const size_t HWo = (size_t)e->Hout * e->Wout;
     OrnStepCur *cur = e->cur + cur_idx;
     if (adv_count > 0) {
-        hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, sched, cursor, n_slots, d.beta1, d.beta2, e->cur, adv_count, e->sc);
+        hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, sched, cursor, n_slots, d.beta1, d.beta2, e->cur, adv_count, e->sc /* all entries */);
         ORN_LAUNCH_CHECK("advance");
     }
+    OrnScaleState *const sc = e->sc + cur_idx;          // this step's entry: its own flag, the shared scale
     const int *fidx = &cur->frame;
     ORN_TRY(forward(e, embeds, fidx, true, st));
     const int nl = d.n_layers, ff = e->ff;
     OrnLossFinalJob fin = {};
     ORN_TRY(orn_launch_loss(e->img, frames, fidx, 3 * HWo, 1, 3, e->Hout, e->Wout, d.loss_type, 1.0f, e->stats, e->dimg,
-                            e->loss_ws, st, cur, stats_out, e->sc, d.loss_type == ORN_LOSS_FUSION6 ? e->tstats : nullptr,
+                            e->loss_ws, st, cur, stats_out, sc, d.loss_type == ORN_LOSS_FUSION6 ? e->tstats : nullptr,
                             ff < nl ? &fin : nullptr));     // 16-bit engine: the finalize stage rides on the head's backward launch
     if (ff < nl)
         ORN_TRY(e->ops->head_bwd(e->L[nl - 1].zb, P + d.head_w, e->img, e->dimg, e->Cn_last, e->Hout, e->Wout, d.sigmoid,
-                                 d.layer[nl - 1].s, e->gs, e->L[nl - 1].dypad, nullptr, nullptr, e->head_ws, st, e->sc, &fin));   // dW / db: finished with the wgrad batch
+                                 d.layer[nl - 1].s, e->gs, e->L[nl - 1].dypad, nullptr, nullptr, e->head_ws, st, sc, &fin));   // dW / db: finished with the wgrad batch
     static const bool no_head_fuse = getenv("ORN_F32_HEAD_UNFUSED") != nullptr;       // tools/probes A/B
     const bool head_fused32 = ff >= nl && e->head_ws && d.layer[nl - 1].s == 2 && !no_head_fuse;
     const OrnHeadBwdFuse hfuse = {P + d.head_w, e->img, e->dimg, d.sigmoid, G + d.head_w, G + d.head_b, e->head_ws};
@@ -538,12 +550,12 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
                 ORN_TRY(e->ops->conv_dgrad(b.dypad, b.wd, l.H, l.W, l.O, ORN_FAST_C, nullptr, nullptr, 1, e->dxn, st, l.C, nullptr, nullptr));
                 if (!e->stage0)
                 ORN_TRY(e->ops->to_nchw_f32(e->dxn, l.C, ORN_FAST_C, l.H, l.W, e->ops->dgrad_f32_slabs(l.H, l.W, l.O), 1.0f / e->gs, dx,
-                                            st, e->sc));
+                                            st, sc));
             }
         } else if (e->stage0) {
             const orn_layer_desc &l1 = d.layer[1];
             ORN_TRY(orn_launch_stage0_bwd(x, b.wf, b.z, e->dxn, e->ops->dgrad_f32_slabs(l1.H, l1.W, l1.O), ORN_FAST_C, 1.0f / e->gs, l.C, l.O,
-                                          l.H, l.W, l.s, e->scratch + e->stem_ws, nullptr, G + l.w3x3, G + l.b3x3, st, e->sc));
+                                          l.H, l.W, l.s, e->scratch + e->stem_ws, nullptr, G + l.w3x3, G + l.b3x3, st, sc));
         } else
         ORN_TRY(orn_launch_conv_bwd_f32(x, b.wf, b.z, b.da, 1, l.C, l.O, l.H, l.W, l.s, dx, G + l.w3x3, G + l.b3x3, e->scratch, st,
                                         (i == nl - 1 && head_fused32) ? &hfuse : nullptr));
@@ -566,14 +578,14 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
             const orn_layer_desc &l = d.layer[i];
             if (!wgrad_rode[i]) wj[nj++] = OrnWgradJob{e->L[i].xpad, e->L[i].dypad, l.H, l.W, l.C, l.O, l.s, e->L[i].wslab};
         }
-        const OrnHeadFinish hf = {e->head_ws, e->ops->head_bwd_blocks(e->Hout, e->Wout), e->Cn_last, 1.0f / e->gs, G + d.head_w, G + d.head_b, e->sc};
+        const OrnHeadFinish hf = {e->head_ws, e->ops->head_bwd_blocks(e->Hout, e->Wout), e->Cn_last, 1.0f / e->gs, G + d.head_w, G + d.head_b, sc};
         if (e->prof) (void)hipEventRecord(e->prof_ev[4 * ORN_MAX_LAYERS], st);
         ORN_TRY(e->ops->wgrad_batch(nj, wj, st, &hf, &w0job));
         if (e->prof) (void)hipEventRecord(e->prof_ev[4 * ORN_MAX_LAYERS + 1], st);
         OrnWgradReduce wr[ORN_MAX_LAYERS];
         for (int i = ff; i < nl; ++i) {
             const orn_layer_desc &l = d.layer[i];
-            wr[i - ff] = OrnWgradReduce{e->L[i].wslab, l.H, l.W, l.C, l.O, l.s, 1.0f / e->gs, G + l.w3x3, G + l.b3x3, e->sc};
+            wr[i - ff] = OrnWgradReduce{e->L[i].wslab, l.H, l.W, l.C, l.O, l.s, 1.0f / e->gs, G + l.w3x3, G + l.b3x3, sc};
         }
         if (e->prof) (void)hipEventRecord(e->prof_ev[4 * ORN_MAX_LAYERS + 2], st);
         ORN_TRY(e->ops->wgrad_reduce_all(nl - ff, wr, st));
@@ -582,7 +594,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
     if (d.erb) {
         // merge backward of every layer (closed forms): dW3 & dT, then dW2 & dW1, then the slices
         if (d.precision != 0) {
-            ORN_TRY(orn_launch_merge_h16_bwd(e->mh_tables, e->mh_host, st));
+            ORN_TRY(orn_launch_merge_h16_bwd(e->mh_tables, e->mh_host, st, sc));
         } else {
             ORN_TRY(orn_launch_merge_group(e->merge_tables, 2, e->merge_tiles[2], st));
             ORN_TRY(orn_launch_merge_group(e->merge_tables, 3, e->merge_tiles[3], st));
@@ -599,7 +611,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         }
         ORN_TRY(orn_launch_merge_bwd_tail_all(nl, mm, st));
     }
-    ORN_TRY(orn_launch_adam(P, G, e->m, e->v, (size_t)d.n_params, 0.0, 1, cur, d.beta1, d.beta2, d.eps, 1.0f, st, e->gmask, e->sc));
+    ORN_TRY(orn_launch_adam(P, G, e->m, e->v, (size_t)d.n_params, 0.0, 1, cur, d.beta1, d.beta2, d.eps, 1.0f, st, e->gmask, sc, e->sc));
     return 0;
 }
 

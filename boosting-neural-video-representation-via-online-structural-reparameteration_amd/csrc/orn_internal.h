@@ -17,7 +17,8 @@ int orn_launch_head_bwd(const float *a, const float *w, const float *out, const 
                         int sigmoid, float *da, float *dw, float *db, float *ws, hipStream_t st);
 int orn_launch_adam(float *p, const float *g, float *m, float *v, size_t n, double lr, int step, const OrnStepCur *sp,
                     double beta1, double beta2, double eps, float inv_gscale, hipStream_t st, const float *gmask = nullptr,
-                    OrnScaleState *sc = nullptr);   // sc: skip the update while its flag is up
+                    OrnScaleState *sc = nullptr,    // sc: skip the update while its flag is up
+                    OrnScaleState *sc_master = nullptr);   // (engine: the entry that counts skipped steps; default sc itself)
 
 // orn_stage0.hip: the fp32 block below the first 16-bit one (tiny stem image), forward / backward as one launch each
 bool orn_stage0_supported(int C, int O, int H, int W, int s);
@@ -71,7 +72,7 @@ size_t orn_merge_h16_layer_halfs(int C, int O);
 size_t orn_merge_h16_table_bytes();
 size_t orn_merge_h16_host_bytes();
 int orn_merge_h16_build(void *dev_tables, void *host, int n_layers, const OrnMergeLayer *L, void *const *bufs, OrnScaleState *sc);
-int orn_launch_merge_h16_bwd(const void *dev_tables, const void *host, hipStream_t st);
+int orn_launch_merge_h16_bwd(const void *dev_tables, const void *host, hipStream_t st, OrnScaleState *sc = nullptr);   // sc: the launching step's scale-state entry
 const void *orn_merge_h16_pack(const void *host, int *par_blocks, int *t_blocks);
 
 // per-layer elementwise tails of the merge, all layers per launch

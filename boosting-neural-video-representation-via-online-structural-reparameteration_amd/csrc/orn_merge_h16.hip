@@ -266,10 +266,12 @@ const void *orn_merge_h16_pack(const void *host, int *par_blocks, int *t_blocks)
 
 // (parameter-side pack: forward), gradient-side pack, then {dW3, dT}, then {dW2, dW1 partials}; the slices / dW1 sum stay with
 // orn_launch_merge_bwd_tail_all
-int orn_launch_merge_h16_bwd(const void *dev_tables, const void *host, hipStream_t st)
+int orn_launch_merge_h16_bwd(const void *dev_tables, const void *host, hipStream_t st, OrnScaleState *sc)
 {
     const OrnMergeH16 *H = (const OrnMergeH16 *)host;
-    hipLaunchKernelGGL(k_merge_pack, dim3(H->pack_blocks_grad), dim3(256), 0, st, H->pack, (int)MH_TAB_GRAD);     // G -> Gh, GT
+    MhPackAll pack = H->pack;
+    if (sc) pack.sc = sc;                               // the flag of the step that is being launched
+    hipLaunchKernelGGL(k_merge_pack, dim3(H->pack_blocks_grad), dim3(256), 0, st, pack, (int)MH_TAB_GRAD);     // G -> Gh, GT
     ORN_LAUNCH_CHECK("merge_pack");
     const MhGroup *g = (const MhGroup *)dev_tables;
     hipLaunchKernelGGL(k_mgemm_h16, dim3(H->tiles[0]), dim3(256), 0, st, g, H->tiles[0]);

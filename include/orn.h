@@ -248,11 +248,12 @@ ORN_API int orn_engine_train_steps_graph(orn_engine *e, const float *frames, con
  * and halves the scale; 2000 clean steps double it again up to its initial value.  All of it happens on the device, inside
  * the captured step.  out8 (host): {scale, 1/scale, ceiling, flag, steps skipped, clean steps, halvings, 0}; synchronises.
  * Where this differs from GradScaler:
- *  - granularity: the flag is read by every step's Adam but cleared (and the scale changed) only where the device-side schedule
- *    advances, once per graph launch; orn_engine_train_steps_graph replays groups of 4 steps, so the clean steps that FOLLOW an
- *    overflowing one inside the same group are skipped with it (and counted in `steps skipped`); orn_engine_train_step advances
- *    every step;
- *  - `clean steps` is credited when a group is launched, not when it has run (it only paces the re-doubling of the scale);
+ *  - granularity: the flag is PER STEP (one scale-state entry per step of the unrolled graph: an overflowing step skips itself
+ *    only, the clean steps before and behind it in the same graph launch update the parameters), but the scale changes only
+ *    where the device-side schedule advances, once per graph launch (orn_engine_train_steps_graph replays groups of 4 steps;
+ *    orn_engine_train_step advances every step): one halving per group however many of its steps overflowed;
+ *  - Adam's step numbers of a group are fixed when it is launched: a step skipped INSIDE a group leaves the bias corrections of
+ *    the at most 3 steps behind it one count ahead (the next group is exact again);
  *  - the merge backward of the 16-bit modes rounds the UN-scaled weight gradient times 2^14 to IEEE half: |dWf| > 4 raises the
  *    same flag, and no loss scale cures that.  Such a fit has diverged; main_train restores the start of the epoch and
  *    continues in a wider precision (bf16 keeps that operand format, fp32 does not have it);

@@ -84,6 +84,36 @@ def test_a_nan_frame_poisons_nothing(orn, prec):
     assert torch.isfinite(eng.params).all() and not torch.equal(eng.params, p0)
     assert torch.isfinite(eng.stats(12)[8:, 0]).all()
 
+@pytest.mark.parametrize('prec', ['fp32', 'fp16'])
+def test_one_bad_step_skips_only_itself(orn, prec):
+    """The non-finite flag is per step of the unrolled graph: ONE poisoned step inside a group of four skips itself only (the clean
+    steps before and behind it in the same graph launch update the parameters), is counted once, and backs the scale off once."""
+    eng = _small_engine(orn, prec)
+    eng.frames[2, 1, 3, 5] = float('nan')
+    eng.set_schedule([(0, 1, 5e-4), (1, 2, 5e-4), (3, 3, 5e-4), (0, 4, 5e-4),        # clean group
+                      (0, 5, 5e-4), (2, 6, 5e-4), (1, 7, 5e-4), (3, 8, 5e-4),        # second step poisoned
+                      (0, 9, 5e-4), (1, 10, 5e-4), (3, 11, 5e-4), (0, 12, 5e-4)])
+    eng.run(4, graph=True)
+    torch.cuda.synchronize()
+    ref = _small_engine(orn, prec)                              # the same fit without the poisoned step
+    ref.params.copy_(eng.params); ref.adam_m.copy_(eng.adam_m); ref.adam_v.copy_(eng.adam_v)
+    eng.run(4, graph=True)
+    torch.cuda.synchronize()
+    s = eng.scale_state()
+    assert s['skipped'] == 1 and s['flag'] == 1, s
+    st = eng.stats(8)
+    assert torch.isfinite(st[[4, 6, 7], 0]).all() and not torch.isfinite(st[5, 0])
+    # Adam step numbers in the device schedule are those of the launch (5, 6, 7, 8 minus the skips known at the advance: none)
+    ref.set_schedule([(0, 5, 5e-4), (1, 7, 5e-4), (3, 8, 5e-4)])
+    ref.run(1, graph=False); ref.run(1, graph=False); ref.run(1, graph=False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.params).all()
+    assert torch.allclose(eng.params, ref.params, rtol=0, atol=1e-6 if prec == 'fp32' else 1e-4)
+    eng.run(4, graph=True)
+    torch.cuda.synchronize()
+    s2 = eng.scale_state()
+    assert s2['skipped'] == 1 and s2['backoffs'] == 1 and s2['flag'] == 0, s2
+
 
 def test_fp16_fit_matches_fp32_fit_psnr(orn):
     """PSNR parity of a whole fit, fp16 engine vs fp32 engine (the reference's arithmetic), north_star tolerance 0.05 dB:
