@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ORN_VERSION 110          /* 0.1.1 */
+#define ORN_VERSION 120          /* 0.1.2: + orn_loss_target_stats*, orn_engine_set_target_stats (round 3) */
 /* Every entry point below is exported with default visibility; the library is built with -fvisibility=hidden, so these (and
  * the probe-only ones of orn_debug.h) are its whole dynamic symbol table. */
 #define ORN_API __attribute__((visibility("default")))

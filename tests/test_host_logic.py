@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(orn):
     assert declared == set(orn._lib.EXPORTS), declared ^ set(orn._lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name)
-    assert L.orn_version() == 110
+    assert L.orn_version() == 120
     # ... and nothing else: the dynamic symbol table is the C ABI (orn.h + the probe-only orn_debug.h), no kernel stubs
     import subprocess
     dbg = set(re.findall(r'\b(orn_[a-z0-9_]+)\s*\(', open(os.path.join(ROOT, 'include', 'orn_debug.h')).read()))
