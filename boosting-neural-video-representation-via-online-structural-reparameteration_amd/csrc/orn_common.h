@@ -75,6 +75,62 @@ __device__ __forceinline__ float orn_wave_sum(float v)
 
 // Last stem kernel (first linear layer's dW / db from `nslab` partial rows of dh1): one output row per 128 threads.  Shared by
 // k_linear_silu_bwd_w_slabs and the wgrad batch launch that carries it as trailing work-groups (Adam is its only consumer).
+// B == 1, second linear layer of the stem backward, 16 output rows per 256-thread work-group (k_stem_bwd_l2, or trailing
+// work-groups of a later launch: the 16-bit engine runs it inside the batched wgrad launch, since only Adam and the stem's last
+// kernel -- which then trails the slab-reduction launch -- consume its results):
+//   d[o] = (sum_s dy_slabs[s][o]) * silu'(pre[o]);  db[o] = d[o];  dw[o][k] = d[o] * x[k];  partial[wg][k] = sum_o w[o][k] * d[o]
+#define ORN_STEM_ROWS 16
+struct OrnStemL2Job {
+    const float *w, *x, *pre, *dy_slabs; int nslab; size_t slab_ld; int K, N; float *dw, *db, *partial;
+};
+// t in [0, 256); sd: 16 floats of LDS; contains a work-group barrier (every thread of the work-group must call)
+__device__ __forceinline__ void orn_stem_l2_block(const OrnStemL2Job &j, int blk, int t, float *sd)
+{
+    const int o0 = blk * ORN_STEM_ROWS, wave = t >> 6, lane = t & 63, N = j.N, K = j.K;
+    {   // this wave's four rows together: their slab loads (and pre) are in flight at once
+        float v[ORN_STEM_ROWS / 4], pr[ORN_STEM_ROWS / 4];
+        int oc[ORN_STEM_ROWS / 4];
+#pragma unroll
+        for (int i = 0; i < ORN_STEM_ROWS / 4; ++i) {
+            const int o = o0 + wave + 4 * i;
+            oc[i] = o < N ? o : N - 1;
+            pr[i] = j.pre[oc[i]];
+            v[i] = 0.f;
+        }
+        for (int sl = lane; sl < j.nslab; sl += 64) {
+#pragma unroll
+            for (int i = 0; i < ORN_STEM_ROWS / 4; ++i) v[i] += j.dy_slabs[(size_t)sl * j.slab_ld + oc[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < ORN_STEM_ROWS / 4; ++i) {
+            const int r = wave + 4 * i, o = o0 + r;
+            const float tot = orn_wave_sum(v[i]);
+            if (lane == 0) {
+                const float d = o < N ? tot * orn_silu_grad_exact(pr[i]) : 0.f;
+                sd[r] = d;
+                if (o < N) j.db[o] = d;
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = t; k < K; k += 256) {
+        const float xk = j.x[k];
+        float wv[ORN_STEM_ROWS];
+#pragma unroll
+        for (int r = 0; r < ORN_STEM_ROWS; ++r) {      // unconditional (clamped) loads: all sixteen in flight together
+            const int o = o0 + r < N ? o0 + r : N - 1;
+            wv[r] = j.w[(size_t)o * K + k];
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < ORN_STEM_ROWS; ++r) {
+            const int o = o0 + r;
+            if (o < N) j.dw[(size_t)o * K + k] = sd[r] * xk;
+            acc = fmaf(wv[r], sd[r], acc);             // sd[r] = 0 past the last row
+        }
+        j.partial[(size_t)blk * K + k] = acc;
+    }
+}
 struct OrnStemW0Job {
     const float *x; const int *row_idx; size_t row_stride; const float *pre, *dy_slabs; int nslab, K, N; float *dpre, *dw, *db;
 };

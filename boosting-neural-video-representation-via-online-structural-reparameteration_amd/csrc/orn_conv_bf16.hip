@@ -684,14 +684,12 @@ __device__ __forceinline__ void head_finish_body(const float *__restrict__ parti
 }
 
 // The head's dW/db reduction (needed by Adam only) rides along as trailing work-groups: one graph node less.
-struct WgradBPAll { int n; int start[ORN_MAX_LAYERS + 1]; WgradBP p[ORN_MAX_LAYERS]; OrnHeadFinish hf; int hf_blocks; OrnStemW0Job w0; };
+struct WgradBPAll { int n; int start[ORN_MAX_LAYERS + 1]; WgradBP p[ORN_MAX_LAYERS]; OrnHeadFinish hf; int hf_blocks; OrnStemL2Job l2; };
 __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16_all(WgradBPAll a)
 {
-    if ((int)blockIdx.x >= a.start[a.n] + a.hf_blocks) {        // stem: two output rows per work-group
-        extern __shared__ __attribute__((aligned(16))) unsigned char smem_w0[];
-        const int half = threadIdx.x >> 7;
-        orn_stem_w0_row(a.w0, ((int)blockIdx.x - a.start[a.n] - a.hf_blocks) * 2 + half, threadIdx.x & 127,
-                        reinterpret_cast<float *>(smem_w0) + 2 * half);
+    if ((int)blockIdx.x >= a.start[a.n] + a.hf_blocks) {        // stem backward, second linear layer: 16 output rows per work-group
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem_l2[];
+        orn_stem_l2_block(a.l2, (int)blockIdx.x - a.start[a.n] - a.hf_blocks, (int)threadIdx.x, reinterpret_cast<float *>(smem_l2));
         return;
     }
     if ((int)blockIdx.x >= a.start[a.n]) {
@@ -754,9 +752,17 @@ __global__ void k_wgrad_bf16_reduce(const float *__restrict__ slabs, const float
 // that each started cold become one that keeps the whole chip streaming.
 struct WgradReduceAll {
     struct { const float *slabs, *bias_slabs; int S, O, Cn, s2, Cr; float gscale; float *dwf, *dbf; OrnScaleState *sc; } l[ORN_MAX_LAYERS];
+    int n; OrnStemW0Job w0;        // blockIdx.y == n: the stem backward's last kernel, two output rows per work-group (needed by Adam only)
 };
 __global__ void k_wgrad_bf16_reduce_all(WgradReduceAll a)
 {
+    if ((int)blockIdx.y == a.n) {
+        __shared__ float sh_w0[4];
+        if (2 * (int)blockIdx.x >= a.w0.N) return;
+        const int half = threadIdx.x >> 7;
+        orn_stem_w0_row(a.w0, (int)blockIdx.x * 2 + half, threadIdx.x & 127, sh_w0 + 2 * half);
+        return;
+    }
     const auto &l = a.l[blockIdx.y];
     if ((size_t)blockIdx.x * blockDim.x >= (size_t)9 * l.O * 96) return;
     wgrad_reduce_body(l.slabs, l.bias_slabs, l.S, l.O, l.Cn, l.s2, l.Cr, l.gscale, l.dwf, l.dbf, l.sc);
@@ -813,9 +819,9 @@ static int wgrad_fill(WgradBP &p, const h16 *xpad, const h16 *dypad, int H, int 
 }
 
 // slabs only (no reduction), several layers in one launch
-int orn_launch_wgrad_bf16_batch(int n, const OrnWgradJob *J, hipStream_t st, const OrnHeadFinish *hf, const OrnStemW0Job *w0)
+int orn_launch_wgrad_bf16_batch(int n, const OrnWgradJob *J, hipStream_t st, const OrnHeadFinish *hf, const OrnStemL2Job *l2)
 {
-    if (n == 0 && !hf && !w0) return 0;
+    if (n == 0 && !hf && !l2) return 0;
     ORN_REQUIRE(n <= ORN_MAX_LAYERS, "wgrad_batch: %d layers", n);
     WgradBPAll a;
     a.n = n;
@@ -829,8 +835,8 @@ int orn_launch_wgrad_bf16_batch(int n, const OrnWgradJob *J, hipStream_t st, con
     a.hf = OrnHeadFinish{};
     a.hf_blocks = 0;
     if (hf) { a.hf = *hf; a.hf_blocks = 3 * hf->C + 3; total += a.hf_blocks; }
-    a.w0 = OrnStemW0Job{};
-    if (w0) { a.w0 = *w0; total += orn_cdiv(w0->N, 2); }
+    a.l2 = OrnStemL2Job{};
+    if (l2) { a.l2 = *l2; total += orn_cdiv(l2->N, ORN_STEM_ROWS); }
     hipLaunchKernelGGL(k_wgrad_nhwc_bf16_all, dim3(total), dim3(256), WB_LDS_BYTES, st, a);
     ORN_LAUNCH_CHECK("wgrad_nhwc_bf16_all");
     return 0;
@@ -853,9 +859,9 @@ int orn_launch_wgrad_bf16(const h16 *xpad, const h16 *dypad, int H, int W, int C
     return 0;
 }
 
-int orn_launch_wgrad_reduce_all(int n, const OrnWgradReduce *L, hipStream_t st)
+int orn_launch_wgrad_reduce_all(int n, const OrnWgradReduce *L, hipStream_t st, const OrnStemW0Job *w0)
 {
-    if (n == 0) return 0;
+    if (n == 0 && !w0) return 0;
     ORN_REQUIRE(n <= ORN_MAX_LAYERS, "wgrad_reduce_all: %d layers", n);
     WgradReduceAll a;
     size_t mx = 0;
@@ -867,7 +873,10 @@ int orn_launch_wgrad_reduce_all(int n, const OrnWgradReduce *L, hipStream_t st)
         const size_t w = (size_t)9 * L[i].O * 96;
         if (w > mx) mx = w;
     }
-    hipLaunchKernelGGL(k_wgrad_bf16_reduce_all, dim3(orn_cdiv((long)mx, 256), n), dim3(256), 0, st, a);
+    a.n = n;
+    a.w0 = OrnStemW0Job{};
+    if (w0) { a.w0 = *w0; const size_t need = (size_t)orn_cdiv(w0->N, 2) * 256; if (need > mx) mx = need; }
+    hipLaunchKernelGGL(k_wgrad_bf16_reduce_all, dim3(orn_cdiv((long)mx, 256), n + (w0 ? 1 : 0)), dim3(256), 0, st, a);
     ORN_LAUNCH_CHECK("wgrad_bf16_reduce_all");
     return 0;
 }

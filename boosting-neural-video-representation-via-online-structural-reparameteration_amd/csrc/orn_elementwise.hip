@@ -202,66 +202,20 @@ __global__ void k_linear_bwd_x_partial(const float *__restrict__ w, const float 
 }
 
 #define ORN_STEM_CHUNKS 256
-#define ORN_STEM_ROWS 16
 
-// B == 1, second linear layer, one launch: the upstream gradient arrives as `nslab` partial rows (the first block's per-work-group
-// dx shares, or one finished row), 16 output rows per work-group:
-//   d[o] = (sum_s dy_slabs[s][o]) * silu'(pre[o]);  db[o] = d[o];  dw[o][k] = d[o] * x[k];  partial[wg][k] = sum_o w[o][k] * d[o]
+// B == 1, second linear layer, one launch (orn_stem_l2_block, orn_common.h): the upstream gradient arrives as `nslab` partial rows
+// (the first block's per-work-group dx shares, or one finished row), 16 output rows per work-group
 // (was: slab reduction + k_linear_silu_bwd_w + k_linear_bwd_x_partial, three graph nodes of ~5-9 us each)
-__global__ void __launch_bounds__(256)
-k_stem_bwd_l2(const float *__restrict__ w, const float *__restrict__ x, const float *__restrict__ pre, const float *__restrict__ dy_slabs,
-              int nslab, size_t slab_ld, int K, int N, float *__restrict__ dw, float *__restrict__ db, float *__restrict__ partial)
+__global__ void __launch_bounds__(256) k_stem_bwd_l2(OrnStemL2Job j)
 {
     __shared__ float sd[ORN_STEM_ROWS];
-    const int o0 = blockIdx.x * ORN_STEM_ROWS, t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    {   // this wave's four rows together: their slab loads (and pre) are in flight at once
-        float v[ORN_STEM_ROWS / 4], pr[ORN_STEM_ROWS / 4];
-        int oc[ORN_STEM_ROWS / 4];
-#pragma unroll
-        for (int i = 0; i < ORN_STEM_ROWS / 4; ++i) {
-            const int o = o0 + wave + 4 * i;
-            oc[i] = o < N ? o : N - 1;
-            pr[i] = pre[oc[i]];
-            v[i] = 0.f;
-        }
-        for (int sl = lane; sl < nslab; sl += 64) {
-#pragma unroll
-            for (int i = 0; i < ORN_STEM_ROWS / 4; ++i) v[i] += dy_slabs[(size_t)sl * slab_ld + oc[i]];
-        }
-#pragma unroll
-        for (int i = 0; i < ORN_STEM_ROWS / 4; ++i) {
-            const int r = wave + 4 * i, o = o0 + r;
-            const float tot = orn_wave_sum(v[i]);
-            if (lane == 0) {
-                const float d = o < N ? tot * orn_silu_grad_exact(pr[i]) : 0.f;
-                sd[r] = d;
-                if (o < N) db[o] = d;
-            }
-        }
-    }
-    __syncthreads();
-    for (int k = t; k < K; k += 256) {
-        const float xk = x[k];
-        float wv[ORN_STEM_ROWS];
-#pragma unroll
-        for (int r = 0; r < ORN_STEM_ROWS; ++r) {      // unconditional (clamped) loads: all sixteen in flight together
-            const int o = o0 + r < N ? o0 + r : N - 1;
-            wv[r] = w[(size_t)o * K + k];
-        }
-        float acc = 0.f;
-#pragma unroll
-        for (int r = 0; r < ORN_STEM_ROWS; ++r) {
-            const int o = o0 + r;
-            if (o < N) dw[(size_t)o * K + k] = sd[r] * xk;
-            acc = fmaf(wv[r], sd[r], acc);             // sd[r] = 0 past the last row
-        }
-        partial[(size_t)blockIdx.x * K + k] = acc;
-    }
+    orn_stem_l2_block(j, (int)blockIdx.x, (int)threadIdx.x, sd);
 }
 
 int orn_launch_stem_bwd(const float *embed, const int *row_idx, size_t row_stride, const float *w1, const float *pre1,
                         const float *h1, const float *pre2, const float *dh2, int B, int E, int Hd, int Nout,
-                        float *dw0, float *db0, float *dw1, float *db1, float *ws, hipStream_t st, int dh2_nslab, OrnStemW0Job *defer_w0)
+                        float *dw0, float *db0, float *dw1, float *db1, float *ws, hipStream_t st, int dh2_nslab, OrnStemW0Job *defer_w0,
+                        OrnStemL2Job *defer_l2)
 {
     // ws: dpre2 [B*Nout] | dpre1 [B*Hd] | dh1 [B*Hd] | partial [CHUNKS*B*Hd]
     float *dpre2 = ws;
@@ -270,9 +224,12 @@ int orn_launch_stem_bwd(const float *embed, const int *row_idx, size_t row_strid
     float *partial = dh1 + (size_t)B * Hd;
     if (B == 1) {
         const int nwg = orn_cdiv(Nout, ORN_STEM_ROWS);
-        hipLaunchKernelGGL(k_stem_bwd_l2, dim3(nwg), dim3(256), 0, st, w1, h1, pre2, dh2, dh2_nslab, (size_t)Nout, Hd, Nout, dw1, db1,
-                           partial);
-        ORN_LAUNCH_CHECK("stem_bwd_l2");
+        const OrnStemL2Job l2 = {w1, h1, pre2, dh2, dh2_nslab, (size_t)Nout, Hd, Nout, dw1, db1, partial};
+        if (defer_l2 && defer_w0) *defer_l2 = l2;      // the caller runs it as trailing work-groups of a later launch (and w0 behind that one)
+        else {
+            hipLaunchKernelGGL(k_stem_bwd_l2, dim3(nwg), dim3(256), 0, st, l2);
+            ORN_LAUNCH_CHECK("stem_bwd_l2");
+        }
         if (defer_w0) {      // the caller appends this job to a later launch (orn_stem_w0_row)
             *defer_w0 = OrnStemW0Job{embed, row_idx, row_stride, pre1, partial, nwg, E, Hd, dpre1, dw0, db0};
             return 0;
@@ -310,7 +267,7 @@ extern "C" int orn_stem_bwd(const float *embed, const float *w1, const float *pr
     ORN_REQUIRE(embed && w1 && pre1 && h1 && pre2 && dh2 && dw0 && db0 && dw1 && db1 && ws, "stem_bwd: null pointer");
     ORN_REQUIRE(B > 0 && E > 0 && Hd > 0 && Nout > 0, "stem_bwd: bad sizes");
     return orn_launch_stem_bwd(embed, nullptr, 0, w1, pre1, h1, pre2, dh2, B, E, Hd, Nout, dw0, db0, dw1, db1, ws,
-                               (hipStream_t)stream, 1, nullptr);
+                               (hipStream_t)stream, 1, nullptr, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------

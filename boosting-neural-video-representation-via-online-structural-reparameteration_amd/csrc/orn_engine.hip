@@ -563,11 +563,12 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
     }
     // stem backward; with a wgrad batch behind it, its last kernel (needed by Adam only) rides along that launch
     OrnStemW0Job w0job;
+    OrnStemL2Job l2job;
     const bool defer_w0 = ff < nl;
     ORN_TRY(orn_launch_stem_bwd(embeds, fidx, d.embed_len, P + d.stem_w1, e->pre1, e->h1, e->pre2,
                                 e->stage0 ? e->scratch + e->stem_ws : e->dh2, 1, d.embed_len, d.stem_dim, Nout, G + d.stem_w0,
                                 G + d.stem_b0, G + d.stem_w1, G + d.stem_b1, e->scratch, st,
-                                e->stage0 ? orn_stage0_slabs(d.layer[0].O, d.layer[0].s) : 1, defer_w0 ? &w0job : nullptr));
+                                e->stage0 ? orn_stage0_slabs(d.layer[0].O, d.layer[0].s) : 1, defer_w0 ? &w0job : nullptr, defer_w0 ? &l2job : nullptr));
     if (ff < nl) {
         // Weight gradients of every fast layer: nothing on the dgrad chain needs them, so they run here as ONE launch (the
         // small layers' 72 / 216 / 360 work-groups pack behind the last block's 504 instead of leaving CUs idle one launch
@@ -580,7 +581,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         }
         const OrnHeadFinish hf = {e->head_ws, e->ops->head_bwd_blocks(e->Hout, e->Wout), e->Cn_last, 1.0f / e->gs, G + d.head_w, G + d.head_b, sc};
         if (e->prof) (void)hipEventRecord(e->prof_ev[4 * ORN_MAX_LAYERS], st);
-        ORN_TRY(e->ops->wgrad_batch(nj, wj, st, &hf, &w0job));
+        ORN_TRY(e->ops->wgrad_batch(nj, wj, st, &hf, &l2job));
         if (e->prof) (void)hipEventRecord(e->prof_ev[4 * ORN_MAX_LAYERS + 1], st);
         OrnWgradReduce wr[ORN_MAX_LAYERS];
         for (int i = ff; i < nl; ++i) {
@@ -588,7 +589,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
             wr[i - ff] = OrnWgradReduce{e->L[i].wslab, l.H, l.W, l.C, l.O, l.s, 1.0f / e->gs, G + l.w3x3, G + l.b3x3, sc};
         }
         if (e->prof) (void)hipEventRecord(e->prof_ev[4 * ORN_MAX_LAYERS + 2], st);
-        ORN_TRY(e->ops->wgrad_reduce_all(nl - ff, wr, st));
+        ORN_TRY(e->ops->wgrad_reduce_all(nl - ff, wr, st, &w0job));
         if (e->prof) (void)hipEventRecord(e->prof_ev[4 * ORN_MAX_LAYERS + 3], st);
     }
     if (d.erb) {

@@ -8,7 +8,8 @@ int orn_launch_linear_silu(const float *x, const int *row_idx, size_t row_stride
 int orn_launch_stem_bwd(const float *embed, const int *row_idx, size_t row_stride, const float *w1, const float *pre1,
                         const float *h1, const float *pre2, const float *dh2, int B, int E, int Hd, int Nout,
                         float *dw0, float *db0, float *dw1, float *db1, float *ws, hipStream_t st, int dh2_nslab = 1,
-                        OrnStemW0Job *defer_w0 = nullptr);   // defer_w0 (B == 1): the last kernel is returned as a job instead of launched
+                        OrnStemW0Job *defer_w0 = nullptr,    // defer_w0 (B == 1): the last kernel is returned as a job instead of launched
+                        OrnStemL2Job *defer_l2 = nullptr);   // defer_l2 (with defer_w0): so is the first one (it then has to run in an EARLIER launch than w0)
 // dh2_nslab > 1 (B == 1): dh2 holds that many partial rows of Nout floats, summed in fixed order by the first kernel
 size_t orn_stem_bwd_ws_floats(int B, int Hd, int Nout);
 int orn_launch_head_fwd(const float *a, const float *w, const float *b, int B, int C, size_t HW, int sigmoid,
@@ -126,8 +127,8 @@ struct OrnHalfOps {
     size_t (*wgrad_ws_floats)(int H, int W, int O);
     int (*wgrad)(const void *xpad, const void *dypad, int H, int W, int C, int O, int s, float gscale, float *slabs, float *dwf,
                  float *dbf, hipStream_t st);
-    int (*wgrad_batch)(int n, const OrnWgradJob *J, hipStream_t st, const OrnHeadFinish *hf, const OrnStemW0Job *w0);   // several layers' slabs in one launch (+ optional head finish)
-    int (*wgrad_reduce_all)(int n, const OrnWgradReduce *L, hipStream_t st);   // all layers' reductions in one launch
+    int (*wgrad_batch)(int n, const OrnWgradJob *J, hipStream_t st, const OrnHeadFinish *hf, const OrnStemL2Job *l2);   // several layers' slabs in one launch (+ optional head finish, + the stem backward's first kernel)
+    int (*wgrad_reduce_all)(int n, const OrnWgradReduce *L, hipStream_t st, const OrnStemW0Job *w0);   // all layers' reductions in one launch (+ the stem backward's last kernel)
     int (*prep_all)(int n, const OrnPrepLayer *L, hipStream_t st);
     int (*to_nhwc)(const float *src, int C, int Cp, int H, int W, void *dst, hipStream_t st);
     int (*to_nchw_f32)(const float *src, int C, int Cp, int H, int W, int nslab, float scale, float *dst, hipStream_t st, const OrnScaleState *sc);
