@@ -490,8 +490,154 @@ __global__ void __launch_bounds__(256, (F32_MINB > 3 ? 3 : F32_MINB)) k_wgrad_f3
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Second form of the fp32 wgrad for O % 128 == 0 and C % 32 == 0 (the 96-channel layers): work-group tile 128 o x 288 n (32 input
+// channels x 9 taps), wave = 32 o x 288 n = NINE 32x32 accumulator tiles (the 16-bit wgrad's shape).  Per 64-pixel K tile a
+// thread stages 49 floats for 288 MFMAs of its wave (first form: 45 for 128), dy is re-read by 3 n tiles instead of 7 and x by 3
+// o tiles instead of 6: the first form spent a quarter of its time issuing staging loads (its K loop alone: 1.86 of 2.49 ms).
+// ------------------------------------------------------------------------------------------------
+#define W2F_BO 128
+#define W2F_CN 32                      // input channels per n tile (288 = 32 x 9 output columns)
+#define W2F_TH 1                       /* K tile = one row x 32 pixels: 29 staged floats per thread (two rows: 49, and the kernel spills) */
+#define W2F_TW 32
+#define W2F_NPX (W2F_TH * W2F_TW)
+#define W2F_XH (W2F_TH + 2)
+#define W2F_XW (W2F_TW + 2)
+#define W2F_DLD (W2F_NPX + 1)
+__global__ void __launch_bounds__(256, 2) k_wgrad_f32_v2(WgradP p)
+{
+    __shared__ float Ds[W2F_BO][W2F_DLD];
+    __shared__ float Xs[W2F_CN][W2F_XH][W2F_XW];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    // XCD-aware item decode as in the first form: (split, o tile, n tile), n tile fastest
+    const int per_xcd = p.items_per_xcd;
+    const int item = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (((int)blockIdx.x >> 3) >= per_xcd || item >= p.n_items) return;
+    const int n_on = p.n_otiles * p.n_ntiles;
+    const int ksplit = item / n_on, on = item - ksplit * n_on;
+    const int ot = on / p.n_ntiles, nt = on - ot * p.n_ntiles;
+    const int o0 = ot * W2F_BO, c_lo = nt * W2F_CN, n0 = c_lo * 9;
+    const int C = p.C, H = p.H, W = p.W, N = C * 9;
+
+    // per-lane LDS offsets of this lane's nine output columns n = n0 + 32 q + l31 -> (channel, tap)
+    int xoff[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const int nr = q * 32 + l31, c = nr / 9, ij = nr - c * 9, i = ij / 3, j = ij - i * 3;
+        xoff[q] = (c * W2F_XH + i) * W2F_XW + j + hh;
+    }
+    const int doff = (wave * 32 + l31) * W2F_DLD + hh;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    constexpr int DN = (W2F_BO * W2F_NPX) / 256;                              // 32
+    constexpr int XN = (W2F_CN * W2F_XH * W2F_XW + 255) / 256;                // 17
+    float dr[DN], xr[XN];
+    const int tiles_per_img = p.tiles_w * p.tiles_h;
+    const int d_px = t & (W2F_NPX - 1), d_o = t / W2F_NPX;                    // dy element t + 256 it = (o = d_o + (256 / NPX) it, pixel d_px)
+    constexpr int OST = 256 / W2F_NPX;
+    auto gload = [&](const int kt) {
+        // (an opaque copy of the thread index: the index arithmetic below is invariant over the K loop, and hoisted out of it by the
+        // compiler it occupied ~100 registers that the nine accumulator tiles need)
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        const int d_px = tt & (W2F_NPX - 1), d_o = tt / W2F_NPX;
+        const int b = kt / tiles_per_img;
+        const int rem = kt - b * tiles_per_img;
+        const int th = rem / p.tiles_w, tw = rem - th * p.tiles_w;
+        const int h0 = th * W2F_TH, w0 = tw * W2F_TW;
+        const float *xb = p.x + (size_t)b * C * H * W;
+        const float *dyb = p.dy + (size_t)b * p.O * H * W;
+        if (h0 >= 1 && h0 + W2F_TH + 1 <= H && w0 >= 1 && w0 + W2F_TW + 1 <= W) {      // interior tile (wave-uniform)
+            const float *dp = dyb + ((size_t)(o0 + d_o) * H + h0 + (d_px >> 5)) * W + w0 + (d_px & 31);
+            const size_t ostep = (size_t)OST * H * W;
+#pragma unroll
+            for (int it = 0; it < DN; ++it) dr[it] = dp[(size_t)it * ostep];
+            const float *xp = xb + ((size_t)c_lo * H + h0) * W + w0;
+#pragma unroll
+            for (int it = 0; it < XN; ++it) {
+                const int idx = tt + it * 256;
+                const int c = idx / (W2F_XH * W2F_XW);
+                const int rem2 = idx - c * (W2F_XH * W2F_XW);
+                const int r = rem2 / W2F_XW, xx = rem2 - r * W2F_XW;
+                xr[it] = idx < W2F_CN * W2F_XH * W2F_XW ? xp[(c * H + r - 1) * W + xx - 1] : 0.f;
+            }
+            return;
+        }
+#pragma unroll
+        for (int it = 0; it < DN; ++it) {
+            const int gh = h0 + (d_px >> 5), gw = w0 + (d_px & 31);
+            dr[it] = (gh < H && gw < W) ? dyb[((size_t)(o0 + d_o + OST * it) * H + gh) * W + gw] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < XN; ++it) {
+            const int idx = tt + it * 256;
+            const int c = idx / (W2F_XH * W2F_XW);
+            const int rem2 = idx - c * (W2F_XH * W2F_XW);
+            const int r = rem2 / W2F_XW, xx = rem2 - r * W2F_XW;
+            const int gh = h0 + r - 1, gw = w0 + xx - 1;
+            xr[it] = 0.f;
+            if (idx < W2F_CN * W2F_XH * W2F_XW && gh >= 0 && gh < H && gw >= 0 && gw < W)
+                xr[it] = xb[((size_t)(c_lo + c) * H + gh) * W + gw];
+        }
+    };
+    if (ksplit < p.n_ktiles) gload(ksplit);
+    for (int kt = ksplit; kt < p.n_ktiles; kt += p.S) {
+        if (kt != ksplit) __syncthreads();               // everyone is done with the previous tile's LDS image
+#pragma unroll
+        for (int it = 0; it < DN; ++it) Ds[d_o + OST * it][d_px] = dr[it];
+#pragma unroll
+        for (int it = 0; it < XN; ++it) {
+            const int idx = t + it * 256;
+            if (idx < W2F_CN * W2F_XH * W2F_XW) (&Xs[0][0][0])[idx] = xr[it];
+        }
+        __syncthreads();
+        if (kt + p.S < p.n_ktiles) gload(kt + p.S);
+        const float *dsp = &Ds[0][0] + doff;
+        const float *xs = &Xs[0][0][0];
+#pragma unroll
+        for (int r = 0; r < W2F_TH; ++r)
+#pragma unroll 4
+            for (int x2 = 0; x2 < W2F_TW; x2 += 2) {
+                const float a = dsp[r * W2F_TW + x2];
+#pragma unroll
+                for (int q = 0; q < 9; ++q)
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xs[xoff[q] + r * W2F_XW + x2], acc[q], 0, 0, 0);
+            }
+    }
+    float *out = p.partial + (size_t)ksplit * p.O * N;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const int n = n0 + q * 32 + l31;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int o = o0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+            out[(size_t)o * N + n] = acc[q][reg];
+        }
+    }
+}
+
+static bool wgrad_v2_ok(int C, int O)
+{
+    static const bool off = getenv("ORN_F32_WGRAD_V1") != nullptr;      // tools/probes A/B
+    return !off && O % W2F_BO == 0 && C % W2F_CN == 0;
+}
+
 static int wgrad_split(int B, int C, int O, int H, int W)
 {
+    if (wgrad_v2_ok(C, O)) {
+        const int n_ktiles = B * orn_cdiv(H, W2F_TH) * orn_cdiv(W, W2F_TW);
+        const int tiles = (O / W2F_BO) * (C / W2F_CN);
+        int S = 512 / tiles;                               // one full round of two work-groups per CU
+        if (S > n_ktiles) S = n_ktiles;
+        return S < 1 ? 1 : S;
+    }
     const int n_ktiles = B * orn_cdiv(H, WG_TH) * orn_cdiv(W, WG_TW);
     const int tiles = orn_cdiv(O, WG_BO) * orn_cdiv(C * 9, WG_BN);
     int S = orn_cdiv(1024, tiles);
@@ -541,6 +687,16 @@ int orn_launch_conv_bwd_f32(const float *x, const float *wf, const float *z, con
     WgradP p;
     p.x = x; p.dy = dy; p.partial = slabs;
     p.B = B; p.C = C; p.O = O; p.H = H; p.W = W;
+    if (wgrad_v2_ok(C, O)) {
+        p.tiles_w = orn_cdiv(W, W2F_TW); p.tiles_h = orn_cdiv(H, W2F_TH);
+        p.n_ktiles = B * p.tiles_w * p.tiles_h;
+        p.S = S;
+        p.n_ntiles = C / W2F_CN; p.n_otiles = O / W2F_BO;
+        p.n_items = p.n_otiles * p.n_ntiles * S;
+        p.items_per_xcd = orn_cdiv(p.n_items, 8);
+        hipLaunchKernelGGL(k_wgrad_f32_v2, dim3(p.items_per_xcd * 8), dim3(256), 0, st, p);
+        ORN_LAUNCH_CHECK("wgrad_f32_v2");
+    } else {
     p.tiles_w = orn_cdiv(W, WG_TW); p.tiles_h = orn_cdiv(H, WG_TH);
     p.n_ktiles = B * p.tiles_w * p.tiles_h;
     p.S = S;
@@ -550,6 +706,7 @@ int orn_launch_conv_bwd_f32(const float *x, const float *wf, const float *z, con
     p.items_per_xcd = orn_cdiv(p.n_items, 8);
     hipLaunchKernelGGL(k_wgrad_f32, dim3(p.items_per_xcd * 8), dim3(256), 0, st, p);
     ORN_LAUNCH_CHECK("wgrad_f32");
+    }
     ORN_TRY(orn_launch_reduce_rows(slabs, S, (size_t)O * C * 9, (size_t)O * C * 9, dwf, st));
 
     if (dx) {
