@@ -539,6 +539,15 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_f32_v2(WgradP p)
     constexpr int DN = (W2F_BO * W2F_NPX) / 256;                              // 32
     constexpr int XN = (W2F_CN * W2F_XH * W2F_XW + 255) / 256;                // 17
     float dr[DN], xr[XN];
+    int xo[XN];                              // x patch element -> offset from (channel c_lo, row h0, col w0); INT_MIN: not a patch element
+#pragma unroll
+    for (int it = 0; it < XN; ++it) {
+        const int idx = t + it * 256;
+        const int c = idx / (W2F_XH * W2F_XW);
+        const int rem = idx - c * (W2F_XH * W2F_XW);
+        const int r = rem / W2F_XW, xx = rem - r * W2F_XW;
+        xo[it] = idx < W2F_CN * W2F_XH * W2F_XW ? (c * H + r - 1) * W + xx - 1 : INT_MIN;
+    }
     const int tiles_per_img = p.tiles_w * p.tiles_h;
     const int d_px = t & (W2F_NPX - 1), d_o = t / W2F_NPX;                    // dy element t + 256 it = (o = d_o + (256 / NPX) it, pixel d_px)
     constexpr int OST = 256 / W2F_NPX;
@@ -561,13 +570,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_f32_v2(WgradP p)
             for (int it = 0; it < DN; ++it) dr[it] = dp[(size_t)it * ostep];
             const float *xp = xb + ((size_t)c_lo * H + h0) * W + w0;
 #pragma unroll
-            for (int it = 0; it < XN; ++it) {
-                const int idx = tt + it * 256;
-                const int c = idx / (W2F_XH * W2F_XW);
-                const int rem2 = idx - c * (W2F_XH * W2F_XW);
-                const int r = rem2 / W2F_XW, xx = rem2 - r * W2F_XW;
-                xr[it] = idx < W2F_CN * W2F_XH * W2F_XW ? xp[(c * H + r - 1) * W + xx - 1] : 0.f;
-            }
+            for (int it = 0; it < XN; ++it) xr[it] = xo[it] != INT_MIN ? xp[xo[it]] : 0.f;
             return;
         }
 #pragma unroll
