@@ -32,7 +32,8 @@ struct ConvP {
     const float *x;     // [B, C, H, W]
     const float *w;     // [O, C, 3, 3]
     const float *bias;  // [O] or null
-    float *out;         // EPI_PLAIN: [B,O,H,W];  EPI_PS_SILU: a [B,Cn,H*s,W*s]
+    float *out;         // EPI_PLAIN: [B,O,H,W];  EPI_PS_SILU: a [B,Cn,H*s,W*s] (may be null: z only -- the fp32 engine's last block, whose
+                        //            only consumer, the head, recomputes SiLU(z))
     float *z;           // EPI_PS_SILU: pre-activation (may be null)
     int B, C, O, H, W, s;
     int tiles_w, tiles_h;
@@ -185,7 +186,7 @@ __global__ void __launch_bounds__(256, F32_MINB) k_conv3x3_f32(ConvP p)
                     const int n = o >> 2, si = (o >> 1) & 1;
                     const size_t idx = (((size_t)b * Cn + n) * (H * 2) + (gh * 2 + si)) * (size_t)(W * 2) + (size_t)gw * 2;
                     if (p.z) *reinterpret_cast<float2 *>(p.z + idx) = make_float2(v0, v1);
-                    *reinterpret_cast<float2 *>(p.out + idx) = make_float2(orn_silu_exact(v0), orn_silu_exact(v1));
+                    if (p.out) *reinterpret_cast<float2 *>(p.out + idx) = make_float2(orn_silu_exact(v0), orn_silu_exact(v1));
                 }
                 continue;
             }
@@ -203,7 +204,7 @@ __global__ void __launch_bounds__(256, F32_MINB) k_conv3x3_f32(ConvP p)
                     const int Cn = p.O / ss;
                     const size_t idx = (((size_t)b * Cn + n) * (H * s) + (gh * s + si)) * (size_t)(W * s) + (gw * s + sj);
                     if (p.z) p.z[idx] = v;
-                    p.out[idx] = orn_silu_exact(v);
+                    if (p.out) p.out[idx] = orn_silu_exact(v);
                 }
             }
         }
@@ -637,7 +638,8 @@ static int wgrad_split(int B, int C, int O, int H, int W)
     if (wgrad_v2_ok(C, O)) {
         const int n_ktiles = B * orn_cdiv(H, W2F_TH) * orn_cdiv(W, W2F_TW);
         const int tiles = (O / W2F_BO) * (C / W2F_CN);
-        int S = 512 / tiles;                               // one full round of two work-groups per CU
+        static const int s_env = getenv("ORN_F32_WGRAD_WGS") ? atoi(getenv("ORN_F32_WGRAD_WGS")) : 512;     // tools/probes sweep
+        int S = s_env / tiles;                             // one full round of two work-groups per CU
         if (S > n_ktiles) S = n_ktiles;
         return S < 1 ? 1 : S;
     }

@@ -275,7 +275,8 @@ extern "C" int orn_stem_bwd(const float *embed, const float *w1, const float *pr
 // ------------------------------------------------------------------------------------------------
 #define ORN_HEAD_MAXC 512
 
-template <int V>
+// ZIN: the input is the pre-activation z and a = SiLU(z) is formed here (fp32 engine's training step: the last block stores z only)
+template <int V, bool ZIN = false>
 __global__ void k_head_fwd(const float *__restrict__ a, const float *__restrict__ w, const float *__restrict__ bias, int C,
                            size_t HW, int sigmoid, float *__restrict__ out)
 {
@@ -300,6 +301,10 @@ __global__ void k_head_fwd(const float *__restrict__ a, const float *__restrict_
         } else {
             av[0] = ab[(size_t)c * HW];
         }
+        if (ZIN) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) av[v] = orn_silu_exact(av[v]);
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -320,9 +325,17 @@ __global__ void k_head_fwd(const float *__restrict__ a, const float *__restrict_
 }
 
 int orn_launch_head_fwd(const float *a, const float *w, const float *b, int B, int C, size_t HW, int sigmoid,
-                        float *out, hipStream_t st)
+                        float *out, hipStream_t st, bool z_input)
 {
     ORN_REQUIRE(C <= ORN_HEAD_MAXC, "head: C=%d > %d unsupported", C, ORN_HEAD_MAXC);
+    if (z_input) {
+        if (HW % 4 == 0)
+            hipLaunchKernelGGL((k_head_fwd<4, true>), dim3(orn_cdiv((long)HW / 4, 256), B), dim3(256), 0, st, a, w, b, C, HW, sigmoid, out);
+        else
+            hipLaunchKernelGGL((k_head_fwd<1, true>), dim3(orn_cdiv((long)HW, 256), B), dim3(256), 0, st, a, w, b, C, HW, sigmoid, out);
+        ORN_LAUNCH_CHECK("head_fwd(z)");
+        return 0;
+    }
     if (HW % 4 == 0)
         hipLaunchKernelGGL(k_head_fwd<4>, dim3(orn_cdiv((long)HW / 4, 256), B), dim3(256), 0, st, a, w, b, C, HW, sigmoid, out);
     else
@@ -335,7 +348,7 @@ extern "C" int orn_head_fwd(const float *a, const float *w, const float *b, int 
                             float *out, void *stream)
 {
     ORN_REQUIRE(a && w && b && out && B > 0 && C > 0 && H > 0 && W > 0, "head_fwd: bad arguments");
-    return orn_launch_head_fwd(a, w, b, B, C, (size_t)H * W, sigmoid, out, (hipStream_t)stream);
+    return orn_launch_head_fwd(a, w, b, B, C, (size_t)H * W, sigmoid, out, (hipStream_t)stream, false);
 }
 
 // Backward.  Block = 256 threads x PPT pixels of one batch item.  du kept in registers; per channel c:

@@ -13,7 +13,7 @@ int orn_launch_stem_bwd(const float *embed, const int *row_idx, size_t row_strid
 // dh2_nslab > 1 (B == 1): dh2 holds that many partial rows of Nout floats, summed in fixed order by the first kernel
 size_t orn_stem_bwd_ws_floats(int B, int Hd, int Nout);
 int orn_launch_head_fwd(const float *a, const float *w, const float *b, int B, int C, size_t HW, int sigmoid,
-                        float *out, hipStream_t st);
+                        float *out, hipStream_t st, bool z_input = false);   // z_input: `a` holds the pre-activation, SiLU is applied here
 int orn_launch_head_bwd(const float *a, const float *w, const float *out, const float *dout, int B, int C, size_t HW,
                         int sigmoid, float *da, float *dw, float *db, float *ws, hipStream_t st);
 int orn_launch_adam(float *p, const float *g, float *m, float *v, size_t n, double lr, int step, const OrnStepCur *sp,
