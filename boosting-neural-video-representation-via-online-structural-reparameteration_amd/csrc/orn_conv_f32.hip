@@ -316,6 +316,44 @@ k_silu_bwd_unshuffle(const float *__restrict__ da, const float *__restrict__ z, 
     if (threadIdx.x == 0) partial[((size_t)b * gridDim.x + chunk) * O + o] = tot;
 }
 
+// stride 2: output channels (o, o + 1), o even, are the horizontal sub-pixels sj = 0, 1 of one (n, si): one 8-byte load of da and
+// of z per thread instead of two 4-byte loads 8 bytes apart.  grid: (chunks, O / 2, B)
+__global__ void __launch_bounds__(256)
+k_silu_bwd_unshuffle_s2(const float *__restrict__ da, const float *__restrict__ z, int O, int H, int W,
+                        float *__restrict__ dy, float *__restrict__ partial)
+{
+    __shared__ float sred[16];
+    const int o = 2 * blockIdx.y, b = blockIdx.z, chunk = blockIdx.x;
+    const int n = o >> 2, si = (o >> 1) & 1;
+    const int Cn = O >> 2;
+    const size_t HW = (size_t)H * W;
+    const size_t Ws = (size_t)W * 2;
+    const float *dab = da + ((size_t)b * Cn + n) * HW * 4;
+    const float *zb = z + ((size_t)b * Cn + n) * HW * 4;
+    float *dy0 = dy + ((size_t)b * O + o) * HW, *dy1 = dy0 + HW;
+    float sum0 = 0.f, sum1 = 0.f;
+    const size_t p0 = (size_t)chunk * DY_PPB;
+    for (int i = threadIdx.x; i < DY_PPB; i += 256) {
+        const size_t pix = p0 + i;
+        if (pix < HW) {
+            const int h = (int)(pix / W), w = (int)(pix - (size_t)h * W);
+            const size_t src = (size_t)(h * 2 + si) * Ws + (size_t)w * 2;
+            const float2 d = *reinterpret_cast<const float2 *>(dab + src);
+            const float2 zz = *reinterpret_cast<const float2 *>(zb + src);
+            const float v0 = d.x * orn_silu_grad_exact(zz.x), v1 = d.y * orn_silu_grad_exact(zz.y);
+            dy0[pix] = v0; dy1[pix] = v1;
+            sum0 += v0; sum1 += v1;
+        }
+    }
+    const float t0 = orn_block_sum(sum0, sred);
+    __syncthreads();
+    const float t1 = orn_block_sum(sum1, sred);
+    if (threadIdx.x == 0) {
+        partial[((size_t)b * gridDim.x + chunk) * O + o] = t0;
+        partial[((size_t)b * gridDim.x + chunk) * O + o + 1] = t1;
+    }
+}
+
 // ================================================================================================
 // Weight transform for dgrad: Wd[c][o][i][j] = Wf[o][c][2-i][2-j]  (dx = conv3x3(dy, Wd, pad 1))
 // ================================================================================================
@@ -684,7 +722,8 @@ int orn_launch_conv_bwd_f32(const float *x, const float *wf, const float *z, con
         ORN_TRY(orn_launch_head_bwd_fused_f32(z, head->w, head->out, head->dout, O / 4, H, W, head->sigmoid, dy, dbp, head->dw, head->db,
                                               head->hws, st));
     } else {
-        hipLaunchKernelGGL(k_silu_bwd_unshuffle, dim3(chunks, O, B), dim3(256), 0, st, da, z, O, H, W, s, dy, dbp);
+        if (s == 2) hipLaunchKernelGGL(k_silu_bwd_unshuffle_s2, dim3(chunks, O / 2, B), dim3(256), 0, st, da, z, O, H, W, dy, dbp);
+        else hipLaunchKernelGGL(k_silu_bwd_unshuffle, dim3(chunks, O, B), dim3(256), 0, st, da, z, O, H, W, s, dy, dbp);
         ORN_LAUNCH_CHECK("silu_bwd_unshuffle");
     }
     ORN_TRY(orn_launch_reduce_rows(dbp, B * chunks, (size_t)O, (size_t)O, dbf, st));
