@@ -35,9 +35,15 @@ __global__ void k_reduce_rows(const float *__restrict__ in, int rows, size_t ld,
 {
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    float acc = 0.f;
-    for (int i = 0; i < rows; ++i) acc += in[(size_t)i * ld + j];
-    out[j] = acc;
+    // eight independent partial sums keep eight loads in flight (fixed order: still deterministic)
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int i = 0;
+    for (; i + 8 <= rows; i += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a8[k] += in[(size_t)(i + k) * ld + j];
+    }
+    for (; i < rows; ++i) a8[0] += in[(size_t)i * ld + j];
+    out[j] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
 }
 
 // Many rows, few columns: 32 columns x 32 row-lanes per block; each lane sums rows r = lane (mod 32) in
