@@ -689,6 +689,12 @@ static int wgrad_split(int B, int C, int O, int H, int W)
     return S;
 }
 
+static int dbp_rows(int H, int W)
+{
+    const int a = orn_cdiv((long)H * W, DY_PPB), b = orn_head_bwd_fused_f32_blocks(H, W);
+    return a > b ? a : b;
+}
+
 extern "C" size_t orn_conv3x3_ps_silu_bwd_ws_bytes(int B, int C, int O, int H, int W)
 {
     const size_t HW = (size_t)H * W;
@@ -697,7 +703,7 @@ extern "C" size_t orn_conv3x3_ps_silu_bwd_ws_bytes(int B, int C, int O, int H, i
     f += orn_align((size_t)B * O * HW * 4) / 4;                         // dy
     f += orn_align((size_t)O * C * 9 * 4) / 4;                          // Wd
     f += orn_align((size_t)wgrad_split(B, C, O, H, W) * O * C * 9 * 4) / 4;   // wgrad partial slabs
-    f += orn_align((size_t)B * chunks * O * 4) / 4;                     // dbias partials
+    f += orn_align((size_t)B * dbp_rows(H, W) * O * 4) / 4;             // dbias partials (the producer with more blocks: fused head backward)
     f += orn_align((size_t)orn_conv3x3_f32_nsplit(B, O, C, H, W) * B * C * HW * 4) / 4;   // dgrad channel-split slabs
     return f * 4;
 }
@@ -713,12 +719,14 @@ int orn_launch_conv_bwd_f32(const float *x, const float *wf, const float *z, con
     float *wd = dy + orn_align((size_t)B * O * HW * 4) / 4;
     float *slabs = wd + orn_align((size_t)O * C * 9 * 4) / 4;
     float *dbp = slabs + orn_align((size_t)S * O * C * 9 * 4) / 4;
-    float *dgs = dbp + orn_align((size_t)B * chunks * O * 4) / 4;
+    float *dgs = dbp + orn_align((size_t)B * dbp_rows(H, W) * O * 4) / 4;
 
+    int dbp_n = B * chunks;                           // rows of dbias partials
     if (head) {
         // the last block of the fp32 engine: head backward, SiLU' and the un-shuffle in one pass (dy and the dbias partials land where
-        // k_silu_bwd_unshuffle would have put them; its blocks cover the same DY_PPB pixels)
-        ORN_REQUIRE(B == 1 && s == 2 && orn_head_bwd_fused_f32_blocks(H, W) == chunks, "conv_bwd_f32: fused head backward needs B == 1, s == 2");
+        // k_silu_bwd_unshuffle would have put them; it has more, smaller blocks: dbp_rows)
+        ORN_REQUIRE(B == 1 && s == 2, "conv_bwd_f32: fused head backward needs B == 1, s == 2");
+        dbp_n = orn_head_bwd_fused_f32_blocks(H, W);
         ORN_TRY(orn_launch_head_bwd_fused_f32(z, head->w, head->out, head->dout, O / 4, H, W, head->sigmoid, dy, dbp, head->dw, head->db,
                                               head->hws, st));
     } else {
@@ -726,7 +734,7 @@ int orn_launch_conv_bwd_f32(const float *x, const float *wf, const float *z, con
         else hipLaunchKernelGGL(k_silu_bwd_unshuffle, dim3(chunks, O, B), dim3(256), 0, st, da, z, O, H, W, s, dy, dbp);
         ORN_LAUNCH_CHECK("silu_bwd_unshuffle");
     }
-    ORN_TRY(orn_launch_reduce_rows(dbp, B * chunks, (size_t)O, (size_t)O, dbf, st));
+    ORN_TRY(orn_launch_reduce_rows(dbp, dbp_n, (size_t)O, (size_t)O, dbf, st));
 
     WgradP p;
     p.x = x; p.dy = dy; p.partial = slabs;

@@ -467,9 +467,9 @@ int orn_launch_head_bwd(const float *a, const float *w, const float *out, const 
 //   dy[o = 4 n + 2 si + sj][h][w] = dz[n][2 h + si][2 w + sj];  head dW[k][n] += du[k] a;  head db[k] += du[k];  conv dbias[o] += dy
 // The unfused pair (k_head_bwd: read a, write da; k_silu_bwd_unshuffle: read da and z, write dy) moved 5 activation-sized
 // tensors through HBM (1.77 GB at 720p, 750 us); this one moves 2 (z in, dy out).
-// Block = 512 threads x 4 low-res pixels (= the 2048 pixels of one dbias-partial chunk of orn_conv_f32.hip); partials in fixed order.
-#define HF_PPT 4
-#define HF_THREADS 512
+// Block = 256 threads x 2 low-res pixels; partials in fixed order.
+#define HF_PPT 2                      /* 512 low-res pixels per work-group: 450 work-groups at 720p (2048 pixels per work-group left */
+#define HF_THREADS 256                /* half the CUs idle: 306 us) */
 __global__ void __launch_bounds__(HF_THREADS)
 k_head_bwd_fused_f32(const float *__restrict__ z, const float *__restrict__ w, const float *__restrict__ out,
                      const float *__restrict__ dout, int Cn, int H, int W, int sigmoid, float *__restrict__ dy,
