@@ -58,11 +58,20 @@ __device__ __forceinline__ float orn_silu_grad(float z)
     return s * (1.0f + z * (1.0f - s));
 }
 
-// exact-mode variants (accurate expf): used by the fp32 path
-__device__ __forceinline__ float orn_silu_exact(float z) { return z / (1.0f + expf(-z)); }
+// exact-mode variants (accurate expf): used by the fp32 path.  The quotient 1 / (1 + e^-z) is v_rcp_f32 + one Newton step (error
+// below 1 ulp of the reciprocal) instead of the IEEE division sequence (~10 instructions): the kernels that evaluate SiLU per
+// element (fp32 head forward / fused backward, conv epilogues) are bound by exactly these instructions.  d = +inf (z < -88) keeps
+// the plain reciprocal 0: the Newton step would form inf * 0.
+__device__ __forceinline__ float orn_sigmoid_exact(float z)
+{
+    const float d = 1.0f + expf(-z);
+    const float r = __builtin_amdgcn_rcpf(d);
+    return d < 3.0e38f ? fmaf(r, fmaf(-d, r, 1.0f), r) : r;
+}
+__device__ __forceinline__ float orn_silu_exact(float z) { return z * orn_sigmoid_exact(z); }
 __device__ __forceinline__ float orn_silu_grad_exact(float z)
 {
-    const float s = 1.0f / (1.0f + expf(-z));
+    const float s = orn_sigmoid_exact(z);
     return s * (1.0f + z * (1.0f - s));
 }
 

@@ -531,8 +531,8 @@ k_head_bwd_fused_f32(const float *__restrict__ z, const float *__restrict__ w, c
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float zz = (q & 1) ? zv[i][q >> 1].y : zv[i][q >> 1].x;
-                const float sg = 1.0f / (1.0f + expf(-zz));
-                const float a = zz * sg;                                           // (== orn_silu_exact up to the division's rounding: see the test tolerance)
+                const float sg = orn_sigmoid_exact(zz);
+                const float a = zz * sg;                                           // == orn_silu_exact(zz): what the forward's head read
                 const float da = fmaf(w2, du[2][i][q], fmaf(w1, du[1][i][q], w0 * du[0][i][q]));
                 const float dz = da * (sg * (1.0f + zz * (1.0f - sg)));             // orn_silu_grad_exact
                 s0 = fmaf(du[0][i][q], a, s0);
