@@ -367,6 +367,35 @@ __global__ void k_flip_transpose_w(const float *__restrict__ wf, int O, int C, f
     wd[((long)c * O + o) * 9 + (8 - ij)] = wf[idx];
 }
 
+// all layers' dgrad weight transforms in one launch (blockIdx.y = layer): five 5-us graph nodes become one
+struct FlipAll { int n; struct { const float *wf; float *wd; int O, C; } l[ORN_MAX_LAYERS]; };
+__global__ void k_flip_transpose_w_all(FlipAll a)
+{
+    const auto &l = a.l[blockIdx.y];
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)l.O * l.C * 9) return;
+    const int ij = (int)(idx % 9);
+    const long oc = idx / 9;
+    const int c = (int)(oc % l.C), o = (int)(oc / l.C);
+    l.wd[((long)c * l.O + o) * 9 + (8 - ij)] = l.wf[idx];
+}
+int orn_launch_flip_transpose_all(int n, const float *const *wf, float *const *wd, const int *O, const int *C, hipStream_t st)
+{
+    if (n == 0) return 0;
+    ORN_REQUIRE(n <= ORN_MAX_LAYERS, "flip_transpose_all: %d layers", n);
+    FlipAll a;
+    a.n = n;
+    long mx = 0;
+    for (int i = 0; i < n; ++i) {
+        a.l[i].wf = wf[i]; a.l[i].wd = wd[i]; a.l[i].O = O[i]; a.l[i].C = C[i];
+        const long w = (long)O[i] * C[i] * 9;
+        if (w > mx) mx = w;
+    }
+    hipLaunchKernelGGL(k_flip_transpose_w_all, dim3(orn_cdiv(mx, 256), n), dim3(256), 0, st, a);
+    ORN_LAUNCH_CHECK("flip_transpose_w_all");
+    return 0;
+}
+
 // ================================================================================================
 // wgrad: dW[o, n=(c,ij)] = sum_{b,h,w} dy[b,o,h,w] * x[b,c,h+i-1,w+j-1]
 // D rows = o (A operand = dy), D cols = n (B operand = shifted x), K = pixels.
@@ -710,7 +739,7 @@ extern "C" size_t orn_conv3x3_ps_silu_bwd_ws_bytes(int B, int C, int O, int H, i
 
 int orn_launch_conv_bwd_f32(const float *x, const float *wf, const float *z, const float *da, int B, int C, int O,
                             int H, int W, int s, float *dx, float *dwf, float *dbf, float *ws, hipStream_t st,
-                            const OrnHeadBwdFuse *head)
+                            const OrnHeadBwdFuse *head, const float *wd_ready)
 {
     const size_t HW = (size_t)H * W;
     const int chunks = orn_cdiv((long)HW, DY_PPB);
@@ -762,7 +791,8 @@ int orn_launch_conv_bwd_f32(const float *x, const float *wf, const float *z, con
     ORN_TRY(orn_launch_reduce_rows(slabs, S, (size_t)O * C * 9, (size_t)O * C * 9, dwf, st));
 
     if (dx) {
-        hipLaunchKernelGGL(k_flip_transpose_w, dim3(orn_cdiv((long)O * C * 9, 256)), dim3(256), 0, st, wf, O, C, wd);
+        if (wd_ready) wd = const_cast<float *>(wd_ready);      // (the engine flips every layer's kernel in one launch)
+        else hipLaunchKernelGGL(k_flip_transpose_w, dim3(orn_cdiv((long)O * C * 9, 256)), dim3(256), 0, st, wf, O, C, wd);
         ORN_LAUNCH_CHECK("flip_transpose_w");
         ORN_TRY(orn_launch_conv3x3_f32(dy, wd, nullptr, B, O, C, H, W, 1, EPI_PLAIN, nullptr, dx, st, dgs));
     }

@@ -11,6 +11,7 @@ struct LayerBuf {
     float *T, *wf, *bf;   // merge products (ERB) -- wf/bf alias the params for vanilla/deploy
     float *w2t;           // tap-major copy of W2 (ERB): the T products read contiguous rows
     float *dT, *dw1p;     // merge backward scratch (ERB)
+    float *wd32;          // fp32 layers: flipped / transposed merged kernel for the dgrad (made for all layers in one launch)
     void *mh16;           // half operand copies of the merge backward (16-bit modes, orn_merge_h16.hip)
     float *dw2t;          // dW2 tap-major [9][O][2C] (16-bit modes)
     float *z, *a;         // block output (pre-activation, activation)          [fp32 layers]
@@ -150,6 +151,7 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
         size_t s1;
         if (i < ff) {
             L[i].z = take(asz); L[i].a = take(asz); L[i].da = take(asz);
+            L[i].wd32 = take(wsz);
             s1 = orn_conv3x3_ps_silu_bwd_ws_bytes(1, l.C, l.O, l.H, l.W) / 4;
             const size_t s0 = al(orn_stem_bwd_ws_floats(1, d->stem_dim, Nout)) + (size_t)orn_stage0_slabs(l.O, l.s) * l.C * l.H * l.W;   // fused first block
             if (s0 > s1) s1 = s0;
@@ -546,6 +548,12 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
     if (ff >= nl && !head_fused32)
         ORN_TRY(orn_launch_head_bwd(e->L[nl - 1].a, P + d.head_w, e->img, e->dimg, 1, e->Cn_last, HWo, d.sigmoid, e->L[nl - 1].da,
                                     G + d.head_w, G + d.head_b, e->scratch, st));
+    if (ff >= nl) {
+        // fp32 engine: every layer's dgrad kernel (flipped taps, transposed) in one launch instead of one per layer
+        const float *wfs[ORN_MAX_LAYERS]; float *wds[ORN_MAX_LAYERS]; int Os[ORN_MAX_LAYERS], Cs[ORN_MAX_LAYERS];
+        for (int i = 0; i < nl; ++i) { wfs[i] = e->L[i].wf; wds[i] = e->L[i].wd32; Os[i] = d.layer[i].O; Cs[i] = d.layer[i].C; }
+        ORN_TRY(orn_launch_flip_transpose_all(nl, wfs, wds, Os, Cs, st));
+    }
     int wgrad_rode[ORN_MAX_LAYERS] = {};
     for (int i = nl - 1; i >= 0; --i) {
         const orn_layer_desc &l = d.layer[i];
@@ -575,7 +583,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
                                           l.H, l.W, l.s, e->scratch + e->stem_ws, nullptr, G + l.w3x3, G + l.b3x3, st, sc));
         } else
         ORN_TRY(orn_launch_conv_bwd_f32(x, b.wf, b.z, b.da, 1, l.C, l.O, l.H, l.W, l.s, dx, G + l.w3x3, G + l.b3x3, e->scratch, st,
-                                        (i == nl - 1 && head_fused32) ? &hfuse : nullptr));
+                                        (i == nl - 1 && head_fused32) ? &hfuse : nullptr, ff >= nl ? b.wd32 : nullptr));
         if (e->prof) (void)hipEventRecord(e->prof_ev[2 * ORN_MAX_LAYERS + 2 * i + 1], st);
     }
     // stem backward; with a wgrad batch behind it, its last kernel (needed by Adam only) rides along that launch

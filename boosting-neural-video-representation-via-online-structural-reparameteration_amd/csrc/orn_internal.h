@@ -94,7 +94,8 @@ int orn_launch_conv3x3_f32(const float *x, const float *w, const float *bias, in
 struct OrnHeadBwdFuse { const float *w, *out, *dout; int sigmoid; float *dw, *db, *hws; };
 int orn_launch_conv_bwd_f32(const float *x, const float *wf, const float *z, const float *da, int B, int C, int O,
                             int H, int W, int s, float *dx, float *dwf, float *dbf, float *ws, hipStream_t st,
-                            const OrnHeadBwdFuse *head = nullptr);
+                            const OrnHeadBwdFuse *head = nullptr, const float *wd_ready = nullptr);   // wd_ready: the flipped / transposed kernel, already made
+int orn_launch_flip_transpose_all(int n, const float *const *wf, float *const *wd, const int *O, const int *C, hipStream_t st);
 int orn_head_bwd_fused_f32_blocks(int H, int W);
 int orn_launch_head_bwd_fused_f32(const float *z, const float *w, const float *out, const float *dout, int Cn, int H, int W,
                                   int sigmoid, float *dy, float *dbp, float *dw, float *db, float *hws, hipStream_t st);
