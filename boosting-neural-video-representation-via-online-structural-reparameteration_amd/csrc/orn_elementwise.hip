@@ -565,6 +565,33 @@ k_head_bwd_fused_f32(const float *__restrict__ z, const float *__restrict__ w, c
 int orn_head_bwd_fused_f32_blocks(int H, int W) { return orn_cdiv((long)H * W, HF_THREADS * HF_PPT); }
 
 // dy [4 Cn][H][W] and dbp [blocks][4 Cn] belong to the caller (the conv backward's workspace); hws: (blocks + 1) x (3 Cn + 3) floats
+// column sums of the head's per-work-group partials straight into dW [3][C] and db [3] (was: reduce_rows + a split kernel);
+// 32 columns x 32 row-lanes per work-group, rows r = lane (mod 32) ascending, then a fixed tree: deterministic
+__global__ void __launch_bounds__(1024) k_head_partials_finish(const float *__restrict__ in, int rows, int n, int C,
+                                                              float *__restrict__ dw, float *__restrict__ db)
+{
+    __shared__ float sm[32][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int j = (int)blockIdx.x * 32 + cx;
+    float acc = 0.f;
+    if (j < n)
+        for (int i = ry; i < rows; i += 32) acc += in[(size_t)i * n + j];
+    sm[ry][cx] = acc;
+    __syncthreads();
+    if (ry < 4) {
+        float r = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r += sm[ry * 8 + k][cx];
+        sm[ry * 8][cx] = r;
+    }
+    __syncthreads();
+    if (ry == 0 && j < n) {
+        const float v = (sm[0][cx] + sm[8][cx]) + (sm[16][cx] + sm[24][cx]);
+        if (j < 3 * C) dw[j] = v;
+        else db[j - 3 * C] = v;
+    }
+}
+
 int orn_launch_head_bwd_fused_f32(const float *z, const float *w, const float *out, const float *dout, int Cn, int H, int W,
                                   int sigmoid, float *dy, float *dbp, float *dw, float *db, float *hws, hipStream_t st)
 {
@@ -575,9 +602,9 @@ int orn_launch_head_bwd_fused_f32(const float *z, const float *w, const float *o
     float *partial = hws, *red = hws + (size_t)nblk * n;
     hipLaunchKernelGGL(k_head_bwd_fused_f32, dim3(nblk), dim3(HF_THREADS), lds, st, z, w, out, dout, Cn, H, W, sigmoid, dy, dbp, partial);
     ORN_LAUNCH_CHECK("head_bwd_fused_f32");
-    ORN_TRY(orn_launch_reduce_rows(partial, nblk, n, n, red, st));
-    hipLaunchKernelGGL(k_head_split_dw, dim3(orn_cdiv((long)n, 128)), dim3(128), 0, st, red, Cn, dw, db);
-    ORN_LAUNCH_CHECK("head_split");
+    (void)red;
+    hipLaunchKernelGGL(k_head_partials_finish, dim3(orn_cdiv((long)n, 32)), dim3(1024), 0, st, partial, nblk, (int)n, Cn, dw, db);
+    ORN_LAUNCH_CHECK("head_partials_finish");
     return 0;
 }
 
