@@ -574,8 +574,8 @@ __global__ void __launch_bounds__(256, (F32_MINB > 3 ? 3 : F32_MINB)) k_wgrad_f3
 #define W2F_DLD (W2F_NPX + 1)
 __global__ void __launch_bounds__(256, 2) k_wgrad_f32_v2(WgradP p)
 {
-    __shared__ float Ds[W2F_BO][W2F_DLD];
-    __shared__ float Xs[W2F_CN][W2F_XH][W2F_XW];
+    __shared__ float Ds[2][W2F_BO][W2F_DLD];            // double-buffered: tile k+1 is stored behind the MFMAs of tile k, one barrier per tile
+    __shared__ float Xs[2][W2F_CN][W2F_XH][W2F_XW];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
@@ -658,20 +658,23 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_f32_v2(WgradP p)
                 xr[it] = xb[((size_t)(c_lo + c) * H + gh) * W + gw];
         }
     };
-    if (ksplit < p.n_ktiles) gload(ksplit);
-    for (int kt = ksplit; kt < p.n_ktiles; kt += p.S) {
-        if (kt != ksplit) __syncthreads();               // everyone is done with the previous tile's LDS image
+    auto lstore = [&](const int bf) {
 #pragma unroll
-        for (int it = 0; it < DN; ++it) Ds[d_o + OST * it][d_px] = dr[it];
+        for (int it = 0; it < DN; ++it) Ds[bf][d_o + OST * it][d_px] = dr[it];
 #pragma unroll
         for (int it = 0; it < XN; ++it) {
             const int idx = t + it * 256;
-            if (idx < W2F_CN * W2F_XH * W2F_XW) (&Xs[0][0][0])[idx] = xr[it];
+            if (idx < W2F_CN * W2F_XH * W2F_XW) (&Xs[bf][0][0][0])[idx] = xr[it];
         }
-        __syncthreads();
-        if (kt + p.S < p.n_ktiles) gload(kt + p.S);
-        const float *dsp = &Ds[0][0] + doff;
-        const float *xs = &Xs[0][0][0];
+    };
+    if (ksplit < p.n_ktiles) { gload(ksplit); lstore(0); }
+    __syncthreads();
+    int bf = 0;
+    for (int kt = ksplit; kt < p.n_ktiles; kt += p.S, bf ^= 1) {
+        const bool has_next = kt + p.S < p.n_ktiles;
+        if (has_next) gload(kt + p.S);
+        const float *dsp = &Ds[bf][0][0] + doff;
+        const float *xs = &Xs[bf][0][0][0];
 #pragma unroll
         for (int r = 0; r < W2F_TH; ++r)
 #pragma unroll 4
@@ -681,6 +684,8 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_f32_v2(WgradP p)
                 for (int q = 0; q < 9; ++q)
                     acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xs[xoff[q] + r * W2F_XW + x2], acc[q], 0, 0, 0);
             }
+        if (has_next) lstore(bf ^ 1);
+        __syncthreads();
     }
     float *out = p.partial + (size_t)ksplit * p.O * N;
 #pragma unroll
