@@ -259,7 +259,7 @@ class StubEngine:
     def set_schedule(self, s):
         self.n = len(s)
 
-    def run(self, n, graph=True):
+    def run(self, n, graph=None):
         time.sleep(0.002 * n)
 
     def stats(self, n):
@@ -267,7 +267,7 @@ class StubEngine:
         return torch.zeros(n, 8)
 
 
-def burn_in(eng, n, graph=True):
+def burn_in(eng, n, graph=None):
     """Setup, not warm-up: n replays of the step on the freshly built engine, after which parameters, Adam moments, step count and
     loss scale are put back, so the W warm-up and K timed steps that follow are exactly the steps they would have been without it.
     The first ~100 steps of a process run 2 % slower than the rest (device clocks and first touches; same box: --steps 20 --warmup 5
@@ -331,7 +331,7 @@ def worker(args):
         dist.init_process_group(args.backend, rank=rank, world_size=world)     # "nccl" = RCCL over xGMI
     device_sync = (lambda: None) if stub else torch.cuda.synchronize
     cfg = CONFIGS[args.config]
-    graph = not args.no_graph
+    graph = {'stream': None, 'graph': True, 'eager': False}['eager' if args.no_graph else args.mode]
 
     eng = StubEngine() if stub else make_engine(seed=1234 + rank, precision=args.precision, cfg=cfg)   # one independent video per rank
     if not stub:
@@ -353,7 +353,8 @@ def worker(args):
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'fp32': 'f32', 'bf16': 'bf16', 'fp16': 'f16'}[args.precision], 'data': 'synthetic',
             'config': {'workload': cfg['name'] + ', stem 512_1, lower_width 96, Fusion6, Adam(0.5,0.999), b=1; one independent video per GPU',
-                       'precision': args.precision, 'hip_graph': graph,
+                       'precision': args.precision, 'hip_graph': bool(graph),
+                       'launch_mode': 'eager' if args.no_graph else args.mode,
                        'timed_region': 'optimiser steps incl. loss, backward, Adam, per-step PSNR; MS-SSIM logging excluded, checkpoint I/O excluded',
                        'train_psnr_mean_timed_steps': psnr_last, 'finite': ok,
                        'whole_step_tflops': world * args.steps / dt * cfg['flop_step'] / 1e12},
@@ -499,7 +500,10 @@ def main():
     ap.add_argument('--fp32-steps', type=int, default=66, help='timed steps of the fp32 record (at most --steps)')
     ap.add_argument('--no-fp32', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--mode', default='stream', choices=['stream', 'graph', 'eager'],
+                    help='stream (default): orn_engine_train_steps, plain launches, the last block\'s weight-gradient chain pipelined on the '
+                         'engine\'s second stream; graph: hipGraph replay of the serial step; eager: one orn_engine_train_step call per step')
+    ap.add_argument('--no-graph', action='store_true', help='same as --mode eager')
     ap.add_argument('--quick', action='store_true', help='headline leg and its roofline only (probes): no sustained / 1080p legs')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'])
     ap.add_argument('--cpu-stub', action='store_true', help='no GPU: exercise launcher + reduction only (tests)')

@@ -74,6 +74,7 @@ _SIGS = {
     'orn_engine_decode': (c_int, [P, P, P, P]),
     'orn_engine_train_step': (c_int, [P, P, P, P, P, P, c_int32, P]),
     'orn_engine_train_steps_graph': (c_int, [P, P, P, P, P, P, c_int32, c_int32, P]),
+    'orn_engine_train_steps': (c_int, [P, P, P, P, P, P, c_int32, c_int32, P]),
     'orn_engine_profile_step': (c_int, [P, P, P, P, P, P, c_int32, P, P]),
     'orn_engine_set_grad_mask': (c_int, [P, P]),
     'orn_engine_set_target_stats': (c_int, [P, P]),

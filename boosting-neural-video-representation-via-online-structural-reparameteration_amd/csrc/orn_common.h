@@ -11,6 +11,11 @@
 
 // ---- error plumbing --------------------------------------------------------------------------
 void orn_set_error(const char *fmt, ...);
+// Kernel-form switches of tools/probes (A/B runs) and of the tests that pin the non-default forms.  Every one that is SET is
+// reported on stderr the first time it is read ("liborn: probe switch ORN_X=.. is active"), so a stray environment variable can
+// not silently change what a fit runs; switches that make results wrong exist only in diagnostic builds (-DORN_PROBE_BUILD).
+const char *orn_probe_env(const char *name);
+int orn_probe_env_int(const char *name, int dflt);
 
 #define ORN_REQUIRE(cond, ...)                         \
     do {                                               \
@@ -242,6 +247,9 @@ struct OrnLossFinalJob {
     const float *part_ssim; int n_ssim; const float *part_l1; int n_l1;    // n_l1 == 0: no job
     double n_elem, n_map; int loss_type; float loss_scale;
     float *stats; const OrnStepCur *cur; float *ring; OrnScaleState *sc;
+    // optional (engine, deferred last block): this step's schedule state and scale, copied for the side branch, which still
+    // reads them after the main stream has advanced to the next step; the copy's flag starts clear
+    OrnStepCur *cur_copy; OrnScaleState *sc_copy;
 };
 // every thread of the work-group calls it (barriers inside); sd: 3 * blockDim.x doubles of LDS; blockDim.x a power of two
 __device__ __forceinline__ void orn_loss_finalize_block(const OrnLossFinalJob &j, double *sd)
@@ -268,6 +276,8 @@ __device__ __forceinline__ void orn_loss_finalize_block(const OrnLossFinalJob &j
         const float psnr = -10.0f * log10f(mse);
         j.stats[0] = loss * j.loss_scale; j.stats[1] = l1; j.stats[2] = mse; j.stats[3] = ss; j.stats[4] = psnr;
         j.stats[5] = 0.f; j.stats[6] = 0.f; j.stats[7] = 0.f;
+        if (j.cur_copy && j.cur) *j.cur_copy = *j.cur;
+        if (j.sc_copy && j.sc) { j.sc_copy->gs = j.sc->gs; j.sc_copy->inv_gs = j.sc->inv_gs; j.sc_copy->gs_max = j.sc->gs_max; j.sc_copy->flag = 0; }
         if (j.ring) {                                  // engine: publish into the per-step ring (slot from the cursor)
             float *r = j.ring + (size_t)j.cur->slot * 8;
             r[0] = loss * j.loss_scale; r[1] = l1; r[2] = mse; r[3] = ss; r[4] = psnr;

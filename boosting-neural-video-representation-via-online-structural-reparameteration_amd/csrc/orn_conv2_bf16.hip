@@ -56,8 +56,6 @@ __device__ __forceinline__ void c2_sfor(F &&f)
 
 namespace HNS {
 
-#include "orn_wgrad_body.h"
-
 #define C2_TH 8
 #define C2_TW 32
 #define C2_PH (C2_TH + 2)
@@ -460,25 +458,6 @@ __global__ void __launch_bounds__(256, 2) k_conv2_nhwc(Conv2P p)
     }
 }
 
-// The dgrad of a block with its OWN wgrad behind it in one launch: the block's weight gradient needs only dy and x of that
-// block, both final before its dgrad starts, and both bodies are four waves at two work-groups per CU.  The dgrad's tiles
-// leave the chip under-filled in their last round (720p: 900 tiles on 512 slots = 1.76 rounds; 230 = 0.45); the wgrad
-// work-groups are dispatched behind them and take the slots as they free up.
-__global__ void __launch_bounds__(256, 2) k_conv2_dgrad_wgrad(Conv2P p, WgradBP wp, int dgrad_blocks)
-{
-    if ((int)blockIdx.x >= dgrad_blocks) {
-        wgrad_body(wp, (int)blockIdx.x - dgrad_blocks);
-        return;
-    }
-    if ((int)blockIdx.x >= p.ptiles) return;          // (the tile count is rounded up to a multiple of 8 for the riders' decode)
-    switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {       // one copy of the body per DMA role (wave-uniform)
-    case 0: c2_body<C2_DGRAD, 0>(p); break;
-    case 1: c2_body<C2_DGRAD, 1>(p); break;
-    case 2: c2_body<C2_DGRAD, 2>(p); break;
-    default: c2_body<C2_DGRAD, 3>(p); break;
-    }
-}
-
 template <int EPI>
 static int c2_launch(const Conv2P &p, int blocks, size_t lds, hipStream_t st, const char *what)
 {
@@ -496,8 +475,7 @@ static int c2_launch(const Conv2P &p, int blocks, size_t lds, hipStream_t st, co
 
 // dgrad of a block whose input image has >= 128 pixel tiles: dx = conv_transpose(dy) x SiLU'(z_prev) into the previous block's
 // dypad.  dypad [H+2][W+2][O], wd [9][96][O] (+ slack: see orn_conv_bf16_wd_elems), O % 32 == 0.
-int orn_launch_dgrad2(const h16 *dypad, const h16 *wd, int H, int W, int O, const h16 *zprev, h16 *dyprev, int sp, hipStream_t st,
-                      const WgradBP *wgrad_rider, int wgrad_blocks)
+int orn_launch_dgrad2(const h16 *dypad, const h16 *wd, int H, int W, int O, const h16 *zprev, h16 *dyprev, int sp, hipStream_t st)
 {
     ORN_REQUIRE(O % C2_CK == 0 && zprev && dyprev && sp >= 1 && sp < 65536 && H % sp == 0 && W % sp == 0 && H < 65536 && W < 65536,
                 "conv_bf16_dgrad: unsupported O=%d sp=%d", O, sp);
@@ -507,19 +485,6 @@ int orn_launch_dgrad2(const h16 *dypad, const h16 *wd, int H, int W, int O, cons
     p.qseg = O / C2_CK;
     p.tiles_w = orn_cdiv(W, C2_TW); p.tiles_h = orn_cdiv(H, C2_TH); p.ptiles = p.tiles_w * p.tiles_h; p.nsplit = 1;
     p.zprev = zprev; p.dyprev = dyprev; p.sp = sp; p.mSp = c2_magic(sp);
-    if (wgrad_rider && wgrad_blocks > 0) {
-        static bool attr_done = false;
-        const size_t lds = C2_LDS > WB_LDS_BYTES ? C2_LDS : WB_LDS_BYTES;
-        if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute((const void *)k_conv2_dgrad_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) { orn_set_error("dgrad2+wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-            attr_done = true;
-        }
-        const int db = (p.ptiles + 7) / 8 * 8;       // the wgrad's XCD-aware decode wants its block range to start on a multiple of 8
-        hipLaunchKernelGGL(k_conv2_dgrad_wgrad, dim3(db + wgrad_blocks), dim3(256), lds, st, p, *wgrad_rider, db);
-        ORN_LAUNCH_CHECK("dgrad2_wgrad_nhwc");
-        return 0;
-    }
     return c2_launch<C2_DGRAD>(p, p.ptiles, C2_LDS, st, "dgrad2_nhwc");
 }
 
@@ -545,7 +510,7 @@ int orn_launch_fwd2(const h16 *xpad, const h16 *wb, const float *bias_p, int H, 
     // The head in this epilogue is correct (tests run it with ORN_HEAD_FUSED=1) but does not pay: 96 SiLUs + 288 FMAs per lane on
     // the vector pipe cost the last block 145 -> 190 us, the 42 us HBM-bound head kernel it replaces included -- and the denser
     // launch drags the clock of its neighbours down (720p step 1.168 -> 1.188 ms on one box).  Off unless asked for.
-    static const bool fuse_head = getenv("ORN_HEAD_FUSED") != nullptr;
+    static const bool fuse_head = orn_probe_env("ORN_HEAD_FUSED") != nullptr;
     if (head && !apad && p.Cn == 96 && fuse_head) {
         p.head_w = head->w; p.head_b = head->b; p.head_out = head->out; p.head_sigmoid = head->sigmoid;
         head->fused = 1;

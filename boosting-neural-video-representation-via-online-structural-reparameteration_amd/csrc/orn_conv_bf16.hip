@@ -557,9 +557,8 @@ static unsigned conv_magic(int d)
 
 // dgrad: N = 96 in one tile (waves 8x1, wave tile 32 px x 96 ch).  The forward launcher lives with its kernel in
 // orn_conv_fwd_bf16.hip (the other MFMA shape).
-int orn_launch_dgrad2(const h16 *dypad, const h16 *wd, int H, int W, int O, const h16 *zprev, h16 *dyprev, int sp, hipStream_t st,
-                      const WgradBP *wgrad_rider = nullptr, int wgrad_blocks = 0);   // orn_conv2_bf16.hip
-static int wgrad_fill(WgradBP &p, const h16 *xpad, const h16 *dypad, int H, int W, int C, int O, int s, float *slabs);
+int orn_launch_dgrad2(const h16 *dypad, const h16 *wd, int H, int W, int O, const h16 *zprev, h16 *dyprev, int sp, hipStream_t st);   // orn_conv2_bf16.hip
+static int wgrad_fill(WgradBP &p, const h16 *xpad, const h16 *dypad, int H, int W, int C, int O, int s, float *slabs, int smax = 0);
 int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p, int H, int W, int Cin, int O, int s,
                              h16 *z, h16 *apad, hipStream_t st, int c_real, OrnHeadFuse *head = nullptr);
 void set_debug_fwd(int flags);
@@ -603,15 +602,11 @@ __global__ void __launch_bounds__(256) k_dgrad_finish(const float *__restrict__ 
 // orn_dgrad_f32_slabs(H, W, O) partial slabs and the result is finished into dyprev (small images).
 // c_real (fp32-output form only): output channels that are not zero padding; <= 32 of them on a chunk-split launch take the
 // all-taps-resident N = 32 form and only channels [0, 32) of the slabs are written
-// wgrad (optional): this block's own weight-gradient job; when the launch taken can carry it (the two-work-groups-per-CU dgrad),
-// its work-groups ride behind the dgrad tiles and *wgrad_done is set -- otherwise the caller batches it later.
 int orn_launch_conv_bf16_dgrad(const h16 *dypad, const h16 *wd, int H, int W, int O, int C, const h16 *zprev,
-                               h16 *dyprev, int sp, float *dx_f32, hipStream_t st, int c_real, const OrnWgradJob *wgrad = nullptr,
-                               int *wgrad_done = nullptr);
+                               h16 *dyprev, int sp, float *dx_f32, hipStream_t st, int c_real);
 int orn_launch_conv_bf16_dgrad(const h16 *dypad, const h16 *wd, int H, int W, int O, int C, const h16 *zprev,
-                               h16 *dyprev, int sp, float *dx_f32, hipStream_t st, int c_real, const OrnWgradJob *wgrad, int *wgrad_done)
+                               h16 *dyprev, int sp, float *dx_f32, hipStream_t st, int c_real)
 {
-    if (wgrad_done) *wgrad_done = 0;
     ORN_REQUIRE(O % CB_CK == 0 && C == 96, "conv_bf16_dgrad: unsupported O=%d C=%d", O, C);
     ConvBP p = {};
     p.dbg = g_conv_dbg;
@@ -636,19 +631,10 @@ int orn_launch_conv_bf16_dgrad(const h16 *dypad, const h16 *wd, int H, int W, in
         return 0;
     }
     ORN_REQUIRE(zprev && dyprev && sp >= 1 && H % sp == 0 && W % sp == 0, "conv_bf16_dgrad: bad epilogue arguments");
-    static const bool form1 = getenv("ORN_DGRAD_FORM1") != nullptr;       // tools/probes: A/B against the one-work-group-per-CU form
+    static const bool form1 = orn_probe_env("ORN_DGRAD_FORM1") != nullptr;       // tools/probes: A/B against the one-work-group-per-CU form
     if (form1) return launch_conv_cfg<8, 1, 1, 3, EPI_B_DGRAD>(p, 1, st);
-    // Measured (round 3, 720p step, same box, tools/probes/ab_step.py): the two combined launches take 17 us less than the
-    // dgrads + the batched wgrad launch they replace (285 + 75 + 25 vs 153 + 48 + 202 us), but the step is 13 us SLOWER
-    // (1.099 vs 1.085 ms): the slab reduction that follows runs 27 -> 34 us (the last block's slabs are written 150 us earlier
-    // and have left the caches) and the tiles behind it lose a little each.  Off unless ORN_WGRAD_RIDE=1.
-    static const bool ride = getenv("ORN_WGRAD_RIDE") != nullptr;
-    if (wgrad && wgrad_done && ride) {
-        WgradBP wp;
-        ORN_TRY(wgrad_fill(wp, (const h16 *)wgrad->xpad, (const h16 *)wgrad->dypad, wgrad->H, wgrad->W, wgrad->C, wgrad->O, wgrad->s, wgrad->slabs));
-        *wgrad_done = 1;
-        return orn_launch_dgrad2(dypad, wd, H, W, O, zprev, dyprev, sp, st, &wp, 3 * wp.n_otiles * wp.S);
-    }
+    // (Round 3 also built the block's own wgrad riding behind these dgrad tiles in one launch: the two combined launches took 17 us
+    // less than the launches they replaced, the STEP 13 us more -- DESIGN 4.5; removed in round 4.)
     return orn_launch_dgrad2(dypad, wd, H, W, O, zprev, dyprev, sp, st);       // two work-groups per CU: orn_conv2_bf16.hip
 }
 
@@ -768,14 +754,14 @@ __global__ void k_wgrad_bf16_reduce_all(WgradReduceAll a)
     wgrad_reduce_body(l.slabs, l.bias_slabs, l.S, l.O, l.Cn, l.s2, l.Cr, l.gscale, l.dwf, l.dbf, l.sc);
 }
 
-int orn_wgrad_bf16_split(int H, int W, int O)
+int orn_wgrad_bf16_split(int H, int W, int O, int smax = 0)
 {
     // S slabs of 9*O*96 floats are written and re-read: keep >= 8 K tiles per work-group so the slab traffic
     // stays small next to the layer's own data, up to one full wave of work-groups (2 per CU)
     const int n_ktiles = orn_cdiv(H, WB_TH) * orn_cdiv(W, WB_TW);
     const int per = 3 * orn_cdiv(O, WB_BO);
     int S = (512 / per) / 8 * 8;
-    static const int s_env = getenv("ORN_WGRAD_SMAX") ? atoi(getenv("ORN_WGRAD_SMAX")) : 0;      // tools/probes: split-K sweep
+    static const int s_env = orn_probe_env_int("ORN_WGRAD_SMAX", 0);      // tools/probes: split-K sweep
     if (s_env > 0 && S > s_env) S = s_env;
     // measured in the 720p step: a full wave of work-groups (56 slabs) makes the slab write + re-read cost more than the idle
     // slots do -- L3 (900 K tiles): 40 slabs beat 56 by 17 us; L4 (3600 K tiles), since the DMA prefetch of the K loop works:
@@ -783,10 +769,11 @@ int orn_wgrad_bf16_split(int H, int W, int O)
     if (S > 40) S = 40;
     // layers under 2000 K tiles (720p L3: 900): 24 slabs -- the wgrad launch does not notice (all layers share it), the reduction
     // reads less: 40 / 32 / 24 = 35 / 32 / 30 us
-    static const int s_small = getenv("ORN_WGRAD_SMAX_SMALL") ? atoi(getenv("ORN_WGRAD_SMAX_SMALL")) : 24;   // tools/probes override
+    static const int s_small = orn_probe_env_int("ORN_WGRAD_SMAX_SMALL", 24);   // tools/probes override
     if (n_ktiles < 2000 && S > s_small) S = s_small;
     const int by_work = (n_ktiles / 8) / 8 * 8;
     if (S > by_work) S = by_work;
+    if (smax >= 8 && S > smax) S = smax / 8 * 8;   // caller's cap (the engine's side branch runs the last block on fewer, longer work-groups)
     if (S < 8) S = 8;
     return S;
 }
@@ -795,7 +782,7 @@ size_t orn_wgrad_bf16_ws_floats(int H, int W, int O) { return (size_t)orn_wgrad_
 
 // dwf [O][C][3][3] and dbf [O] (PyTorch channel order), both overwritten.  C <= 96 real channels; xpad always has 96
 // channels per pixel (zeros above C).
-static int wgrad_fill(WgradBP &p, const h16 *xpad, const h16 *dypad, int H, int W, int C, int O, int s, float *slabs)
+static int wgrad_fill(WgradBP &p, const h16 *xpad, const h16 *dypad, int H, int W, int C, int O, int s, float *slabs, int smax)
 {
     // O % 32: a ragged last 128-channel tile reads up to 96 channels past the last pixel's: dypad must be readable for 96
     // elements behind its end (the engine and the per-op hooks pad it)
@@ -804,7 +791,7 @@ static int wgrad_fill(WgradBP &p, const h16 *xpad, const h16 *dypad, int H, int 
     p.xpad = xpad; p.dypad = dypad; p.slabs = slabs; p.H = H; p.W = W; p.O = O;
     p.tiles_w = orn_cdiv(W, WB_TW);
     p.n_ktiles = p.tiles_w * orn_cdiv(H, WB_TH);
-    p.S = orn_wgrad_bf16_split(H, W, O);
+    p.S = orn_wgrad_bf16_split(H, W, O, smax);
     p.bias_slabs = slabs + (size_t)p.S * 9 * O * 96;
     p.n_otiles = orn_cdiv(O, WB_BO);
     static bool attr_done = false;
@@ -827,7 +814,7 @@ int orn_launch_wgrad_bf16_batch(int n, const OrnWgradJob *J, hipStream_t st, con
     a.n = n;
     int total = 0;
     for (int i = 0; i < n; ++i) {
-        ORN_TRY(wgrad_fill(a.p[i], (const h16 *)J[i].xpad, (const h16 *)J[i].dypad, J[i].H, J[i].W, J[i].C, J[i].O, J[i].s, J[i].slabs));
+        ORN_TRY(wgrad_fill(a.p[i], (const h16 *)J[i].xpad, (const h16 *)J[i].dypad, J[i].H, J[i].W, J[i].C, J[i].O, J[i].s, J[i].slabs, J[i].smax));
         a.start[i] = total;
         total += 3 * a.p[i].n_otiles * a.p[i].S;        // S % 8 == 0: every start is a multiple of 8
     }
@@ -866,7 +853,7 @@ int orn_launch_wgrad_reduce_all(int n, const OrnWgradReduce *L, hipStream_t st, 
     WgradReduceAll a;
     size_t mx = 0;
     for (int i = 0; i < n; ++i) {
-        const int S = orn_wgrad_bf16_split(L[i].H, L[i].W, L[i].O), s2 = L[i].s * L[i].s;
+        const int S = orn_wgrad_bf16_split(L[i].H, L[i].W, L[i].O, L[i].smax), s2 = L[i].s * L[i].s;
         a.l[i].slabs = L[i].slabs; a.l[i].bias_slabs = L[i].slabs + (size_t)S * 9 * L[i].O * 96;
         a.l[i].S = S; a.l[i].O = L[i].O; a.l[i].Cn = L[i].O / s2; a.l[i].s2 = s2; a.l[i].Cr = L[i].C; a.l[i].gscale = L[i].gscale;
         a.l[i].dwf = L[i].dwf; a.l[i].dbf = L[i].dbf; a.l[i].sc = L[i].sc;
@@ -1314,8 +1301,8 @@ static int a_conv_fwd(const void *xpad, const void *wb, const float *bias_p, int
                       hipStream_t st, int c_real, OrnHeadFuse *head)
 { return orn_launch_conv_bf16_fwd((const h16 *)xpad, (const h16 *)wb, bias_p, H, W, Cin, O, s, (h16 *)z, (h16 *)apad, st, c_real, head); }
 static int a_conv_dgrad(const void *dypad, const void *wd, int H, int W, int O, int C, const void *zprev, void *dyprev, int sp,
-                        float *dx_f32, hipStream_t st, int c_real, const OrnWgradJob *wgrad, int *wgrad_done)
-{ return orn_launch_conv_bf16_dgrad((const h16 *)dypad, (const h16 *)wd, H, W, O, C, (const h16 *)zprev, (h16 *)dyprev, sp, dx_f32, st, c_real, wgrad, wgrad_done); }
+                        float *dx_f32, hipStream_t st, int c_real)
+{ return orn_launch_conv_bf16_dgrad((const h16 *)dypad, (const h16 *)wd, H, W, O, C, (const h16 *)zprev, (h16 *)dyprev, sp, dx_f32, st, c_real); }
 static int a_wgrad(const void *xpad, const void *dypad, int H, int W, int C, int O, int s, float gscale, float *slabs, float *dwf,
                    float *dbf, hipStream_t st)
 { return orn_launch_wgrad_bf16((const h16 *)xpad, (const h16 *)dypad, H, W, C, O, s, gscale, slabs, dwf, dbf, st); }

@@ -701,7 +701,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_f32_v2(WgradP p)
 
 static bool wgrad_v2_ok(int C, int O)
 {
-    static const bool off = getenv("ORN_F32_WGRAD_V1") != nullptr;      // tools/probes A/B
+    static const bool off = orn_probe_env("ORN_F32_WGRAD_V1") != nullptr;      // tools/probes A/B
     return !off && O % W2F_BO == 0 && C % W2F_CN == 0;
 }
 
@@ -710,7 +710,7 @@ static int wgrad_split(int B, int C, int O, int H, int W)
     if (wgrad_v2_ok(C, O)) {
         const int n_ktiles = B * orn_cdiv(H, W2F_TH) * orn_cdiv(W, W2F_TW);
         const int tiles = (O / W2F_BO) * (C / W2F_CN);
-        static const int s_env = getenv("ORN_F32_WGRAD_WGS") ? atoi(getenv("ORN_F32_WGRAD_WGS")) : 512;     // tools/probes sweep
+        static const int s_env = orn_probe_env_int("ORN_F32_WGRAD_WGS", 512);     // tools/probes sweep
         int S = s_env / tiles;                             // one full round of two work-groups per CU
         if (S > n_ktiles) S = n_ktiles;
         return S < 1 ? 1 : S;

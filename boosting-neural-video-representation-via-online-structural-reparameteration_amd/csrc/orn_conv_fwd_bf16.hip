@@ -554,9 +554,9 @@ int orn_launch_conv_bf16_fwd(const h16 *xpad, const h16 *wb, const float *bias_p
     // the last block (z only) 150 -> 140 us at 720p; blocks that also write the activation copy are neutral at 230 pixel tiles
     // (720p, 180 x 320: 74.2 vs 73.9 us for the two such launches) and gain from ~500 tiles on (1080p: 181 -> 168 us for its
     // three), so those take it from 400 tiles (ORN_FWD2_APAD: always).
-    static const bool form1 = getenv("ORN_FWD_FORM1") != nullptr;         // tools/probes: A/B against this file's kernel
-    static const bool form2_apad = getenv("ORN_FWD2_APAD") != nullptr;
-    static const int min_tiles = getenv("ORN_FWD2_MINTILES") ? atoi(getenv("ORN_FWD2_MINTILES")) : 128;
+    static const bool form1 = orn_probe_env("ORN_FWD_FORM1") != nullptr;         // tools/probes: A/B against this file's kernel
+    static const bool form2_apad = orn_probe_env("ORN_FWD2_APAD") != nullptr;
+    static const int min_tiles = orn_probe_env_int("ORN_FWD2_MINTILES", 128);
     if (!form1 && Cin == 96 && O % 96 == 0 && ptiles >= min_tiles && (!apad || ptiles >= 400 || form2_apad)) {
         const int rc = orn_launch_fwd2(xpad, wb, bias_p, H, W, O, s, z, apad, st, head);
         if (rc != -1) return rc;

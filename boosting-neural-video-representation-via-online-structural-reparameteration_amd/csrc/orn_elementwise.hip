@@ -1,6 +1,7 @@
 // Small HBM-/latency-bound kernels of the hot path: positional encoding (A1), MLP stem (A2),
 // 1x1 head (A5), Adam (A9) and the deterministic reduction helpers everything else shares.
 #include "orn_internal.h"
+#include <stdlib.h>
 #include <math.h>
 #include <string.h>
 
@@ -15,6 +16,19 @@ void orn_set_error(const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+const char *orn_probe_env(const char *name)
+{
+    const char *v = getenv(name);
+    if (v) fprintf(stderr, "liborn: probe switch %s=%s is active (non-default kernel form)\n", name, v);
+    return v;
+}
+
+int orn_probe_env_int(const char *name, int dflt)
+{
+    const char *v = orn_probe_env(name);
+    return v ? atoi(v) : dflt;
 }
 
 extern "C" int orn_version(void) { return ORN_VERSION; }
@@ -632,11 +646,14 @@ template <bool MASK>
 __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
                        size_t n, float step_size_v, float sqrt_bc2_v, const OrnStepCur *__restrict__ sp, float beta1,
                        float omb1, float beta2, float omb2, float eps, float inv_gscale, const float *__restrict__ gmask,
-                       OrnScaleState *sc, OrnScaleState *sc_master)
+                       OrnScaleState *sc, OrnScaleState *sc_master, OrnScaleState *mirror)
 {
     // non-finite gradients somewhere in this step: leave parameters and moments alone (the whole step is skipped)
     if (sc && sc->flag) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) sc_master->skipped += 1;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (sc_master) sc_master->skipped += 1;
+            if (mirror) mirror->flag = 1;       // the side branch's Adam launch of this step follows the same decision
+        }
         return;
     }
     // gmask (optional, 0/1 per parameter): the gradient is multiplied by it -- the prune fine-tune of main_eval.py,
@@ -676,16 +693,17 @@ __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float
 
 int orn_launch_adam(float *p, const float *g, float *m, float *v, size_t n, double lr, int step, const OrnStepCur *sp,
                     double beta1, double beta2, double eps, float inv_gscale, hipStream_t st, const float *gmask, OrnScaleState *sc,
-                    OrnScaleState *sc_master)
+                    OrnScaleState *sc_master, OrnScaleState *mirror, bool count_skip)
 {
+    OrnScaleState *const master = count_skip ? (sc_master ? sc_master : sc) : nullptr;
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     const dim3 gr(orn_cdiv((long)orn_cdiv((long)n, 4), 256));
     if (gmask)
         hipLaunchKernelGGL(k_adam<true>, gr, dim3(256), 0, st, p, g, m, v, n, (float)(lr / bc1), (float)sqrt(bc2), sp, (float)beta1,
-                           (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, inv_gscale, gmask, sc, sc_master ? sc_master : sc);
+                           (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, inv_gscale, gmask, sc, master, mirror);
     else
         hipLaunchKernelGGL(k_adam<false>, gr, dim3(256), 0, st, p, g, m, v, n, (float)(lr / bc1), (float)sqrt(bc2), sp, (float)beta1,
-                           (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, inv_gscale, gmask, sc, sc_master ? sc_master : sc);
+                           (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, inv_gscale, gmask, sc, master, mirror);
     ORN_LAUNCH_CHECK("adam");
     return 0;
 }

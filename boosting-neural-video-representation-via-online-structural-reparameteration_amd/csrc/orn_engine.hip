@@ -43,10 +43,16 @@ struct orn_engine {
     const OrnHalfOps *ops;           // 16-bit fast-path kernels (bf16 or fp16 build)
     float gs;                        // INITIAL gradient scale of the 16-bit gradient tensors (1 for bf16, 2^20 for fp16)
     OrnScaleState *sc;               // device: the live scale + non-finite flag (dynamic loss scaling, skipped steps)
-    void *merge_tables;              // device-resident grouped-GEMM problem tables (ERB)
-    OrnMergeLayer ml[ORN_MAX_LAYERS];   // (ERB) the layers as the merge launchers see them
-    void *mh_tables, *mh_host;       // 16-bit modes: tables of the packed-operand merge backward (device / host)
-    int merge_tiles[4];
+    // (ERB) the grouped merge launches work on a SET of layers: all of them (a serial step, decode), or -- in the pipelined
+    // form of the step, below -- all but the last block on the caller's stream and the last block alone on the side stream
+    struct MergeSet {
+        int n;                          // layers in the set (0: set not built)
+        OrnMergeLayer ml[ORN_MAX_LAYERS];   // the layers as the merge launchers see them
+        int layer[ORN_MAX_LAYERS];      // their indices in the engine
+        void *tables;                   // device-resident grouped-GEMM problem tables
+        int tiles[4];
+        void *mh_tables, *mh_host;      // 16-bit modes: tables of the packed-operand merge backward (device / host)
+    } mset[3];
     int ff;                          // first layer on the bf16 fast path (== n_layers: none)
     float *dxn;                      // fp32 NHWC dgrad output of layer ff (converted to NCHW for the fp32 part)
     size_t stem_ws;                  // floats of `scratch` the stem backward uses (the fused first block's dx slabs sit behind them)
@@ -58,6 +64,26 @@ struct orn_engine {
     const void *g_frames, *g_embeds, *g_sched, *g_cursor, *g_stats;
     int g_slots;
     hipStream_t g_stream;
+    // Pipelined form of the step (orn_engine_train_steps; 16-bit engines with >= 2 blocks on the fast path): the LAST block's
+    // weight gradient, slab reduction, merge backward, Adam update and next merge forward run on a second stream (`side`),
+    // forked off the caller's stream at the end of the backward and joined in front of the last block's forward conv of the
+    // NEXT step.  That chain -- one full-chip MFMA launch and a tail of small ones -- then runs beside the latency-bound
+    // launches of the step boundary (merge backward / Adam / merge forward of the lower blocks, stem, first blocks) instead of
+    // in front of them.  Same arithmetic as the serial step (bit-identical results); what it needs:
+    //   ev_fork   main -> side: dy / x of the last block, the head's partials and the step's copied schedule state are final
+    //   ev_adam   main -> side: the step's skip decision has been taken (the side's Adam launch follows it)
+    //   ev_wgrad  side -> main: the last block's input buffer may be overwritten (by the forward conv of the block below it)
+    //   ev_join   side -> main: the last block's merged kernel (and the head's parameters) of the next step are ready
+    // cur_side / sc_side: this step's schedule entry and loss scale, copied by the loss's finalize stage (the main stream advances
+    // to the next step while the side branch still reads them); sc_side->flag also collects what the side branch's own two
+    // detectors raise behind the main commit (include/orn.h, the loss-scale comment).
+    hipStream_t side;
+    hipEvent_t ev_fork, ev_adam, ev_wgrad, ev_join;
+    OrnStepCur *cur_side;
+    OrnScaleState *sc_side;
+    size_t side_lo;                  // parameters [side_lo, n_params) belong to the side branch's Adam launch (last block + head)
+    bool pipe_ok;                    // this engine can run the pipelined form
+    bool side_busy;                  // a side branch is in flight (joined by the next step's forward or at the end of the call)
     // orn_engine_profile_step: HIP events around every forward conv launch of an eager step
     bool prof;
     hipEvent_t prof_ev[4 * ORN_MAX_LAYERS + 4];      // pairs: forward conv of layer i, dgrad launch of layer i, wgrad batch, its reduction
@@ -186,8 +212,13 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
                    : (ll.s == 2 ? take((size_t)(orn_head_bwd_fused_f32_blocks(ll.H, ll.W) + 1) * (3 * Cn + 3)) : nullptr);
     float *cur = take((sizeof(OrnStepCur) * ORN_GRAPH_UNROLL + 3) / 4 + 16);    // one cursor state per step of the unrolled graph
     float *scs = take(sizeof(OrnScaleState) * ORN_SCALE_SLOTS / 4);     // one entry per step of the unrolled graph (entry 0 = master)
-    float *mtab = d->erb ? take(orn_merge_group_bytes() / 4) : nullptr;
-    float *mhtab = (d->erb && d->precision != 0) ? take(orn_merge_h16_table_bytes() / 4) : nullptr;
+    float *mtab[3], *mhtab[3];
+    for (int k = 0; k < 3; ++k) {
+        mtab[k] = d->erb ? take(orn_merge_group_bytes() / 4) : nullptr;
+        mhtab[k] = (d->erb && d->precision != 0) ? take(orn_merge_h16_table_bytes() / 4) : nullptr;
+    }
+    float *cur_side = take((sizeof(OrnStepCur) + 3) / 4 + 16);
+    float *sc_side = take(sizeof(OrnScaleState) / 4 + 16);
     if (e) {
         e->pre1 = pre1; e->h1 = h1; e->pre2 = pre2; e->h2 = h2; e->dh2 = dh2;
         e->img = img; e->dimg = dimg; e->stats = stats; e->loss_ws = loss_ws; e->scratch = scr; e->head_ws = head_ws;
@@ -199,8 +230,9 @@ static size_t layout(const orn_engine_desc *d, orn_engine *e)
         e->stem_ws = al(orn_stem_bwd_ws_floats(1, d->stem_dim, Nout));
         const orn_layer_desc &l0 = d->layer[0];
         e->stage0 = d->precision != 0 && ff == 1 && d->n_layers > 1 && orn_stage0_supported(l0.C, l0.O, l0.H, l0.W, l0.s);
-        e->merge_tables = mtab;
-        e->mh_tables = mhtab;
+        for (int k = 0; k < 3; ++k) { e->mset[k].tables = mtab[k]; e->mset[k].mh_tables = mhtab[k]; }
+        e->cur_side = (OrnStepCur *)cur_side;
+        e->sc_side = (OrnScaleState *)sc_side;
     }
     return off * 4;
 }
@@ -233,7 +265,9 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
     e->ws = (float *)ws;
     e->graph = nullptr; e->graph_exec = nullptr; e->graph_u = nullptr; e->graph_exec_u = nullptr;
     e->prof = false;
-    e->mh_host = nullptr;
+    for (int k = 0; k < 3; ++k) { e->mset[k].n = 0; e->mset[k].mh_host = nullptr; }
+    e->side = nullptr; e->ev_fork = e->ev_adam = e->ev_wgrad = e->ev_join = nullptr;
+    e->pipe_ok = false; e->side_busy = false; e->side_lo = 0;
     for (int i = 0; i < 4 * ORN_MAX_LAYERS + 4; ++i) e->prof_ev[i] = nullptr;
     e->ops = (d->precision == 2) ? orn_half_ops_f16() : orn_half_ops_bf16();
     e->gs = (d->precision == 2) ? 1048576.0f : 1.0f;
@@ -245,7 +279,35 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
         OrnScaleState s0[ORN_SCALE_SLOTS] = {};
         for (int r = 0; r < ORN_SCALE_SLOTS; ++r) { s0[r].gs = e->gs; s0[r].inv_gs = 1.0f / e->gs; s0[r].gs_max = e->gs; }
         rc = hipMemcpy(e->sc, s0, sizeof(s0), hipMemcpyHostToDevice);
+        if (rc == hipSuccess) rc = hipMemcpy(e->sc_side, s0, sizeof(OrnScaleState), hipMemcpyHostToDevice);
         if (rc != hipSuccess) { orn_set_error("engine_create: scale state upload failed: %s", hipGetErrorString(rc)); delete e; return (int)rc; }
+    }
+    // Can this engine run the pipelined step?  16-bit mode with the last block AND the block below it on the fast path (the
+    // hand-off points are their buffers), gradients present, and an arena in which the last block's tensors and the head's lie
+    // behind everything else (one Adam launch per stream).  ORN_NO_PIPELINE: tools/probes A/B.
+    {
+        const int nl = d->n_layers;
+        const orn_layer_desc &ll = d->layer[nl - 1];
+        bool ok = d->precision != 0 && e->ff < nl - 1 && grads && adam_m && adam_v && orn_probe_env("ORN_NO_PIPELINE") == nullptr;
+        if (ok) {
+            const int64_t lo_all[9] = {ll.w3x3, ll.b3x3, ll.w3x1, ll.b3x1, ll.w1x3, ll.b1x3, ll.w1, ll.w2, ll.w3};
+            int64_t lo = d->n_params;
+            for (int k = 0; k < (d->erb ? 9 : 2); ++k) if (lo_all[k] >= 0 && lo_all[k] < lo) lo = lo_all[k];
+            ok = d->head_w >= lo && d->head_b >= lo && d->stem_w0 < lo && d->stem_b0 < lo && d->stem_w1 < lo && d->stem_b1 < lo && lo % 64 == 0;
+            for (int i = 0; i < nl - 1 && ok; ++i) {
+                const orn_layer_desc &l = d->layer[i];
+                const int64_t o[9] = {l.w3x3, l.b3x3, l.w3x1, l.b3x1, l.w1x3, l.b1x3, l.w1, l.w2, l.w3};
+                for (int k = 0; k < (d->erb ? 9 : 2); ++k) ok = ok && o[k] < lo;
+            }
+            e->side_lo = (size_t)lo;
+        }
+        if (ok) {
+            hipError_t rc = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
+            hipEvent_t *evs[4] = {&e->ev_fork, &e->ev_adam, &e->ev_wgrad, &e->ev_join};
+            for (int k = 0; k < 4 && rc == hipSuccess; ++k) rc = hipEventCreateWithFlags(evs[k], hipEventDisableTiming);
+            if (rc != hipSuccess) { orn_set_error("engine_create: side stream: %s", hipGetErrorString(rc)); orn_engine_destroy(e); return (int)rc; }
+        }
+        e->pipe_ok = ok;
     }
     if (!d->erb)
         for (int i = 0; i < d->n_layers; ++i) {
@@ -254,10 +316,8 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
             e->L[i].bf = params + d->layer[i].b3x3;
         }
     else {
-        OrnMergeLayer *ml = e->ml;
-        for (int i = 0; i < d->n_layers; ++i) {
+        auto fill = [&](int i, OrnMergeLayer &m, bool half_in_S) {
             const orn_layer_desc &l = d->layer[i];
-            OrnMergeLayer &m = ml[i];
             m.C = l.C; m.O = l.O;
             m.w3x3 = params + l.w3x3; m.w3x1 = params + l.w3x1; m.w1x3 = params + l.w1x3;
             m.w1 = params + l.w1; m.w2 = params + l.w2; m.w3 = params + l.w3;
@@ -269,20 +329,31 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
             m.dw2t = e->L[i].dw2t;
             m.half_kind = 0; m.s2 = l.s * l.s; m.Cp = ORN_FAST_C; m.wb = m.wd = nullptr; m.biasp = nullptr;
             // the merged kernel's 16-bit operand copies: rider work-groups of the first block's launch (forward()) when that
-            // launch exists, else the epilogue of the merge's S product
-            if (i >= e->ff && !e->stage0) {
+            // launch exists, else (and always on the side stream) the epilogue of the merge's S product
+            if (i >= e->ff && half_in_S) {
                 m.half_kind = d->precision; m.wb = e->L[i].wb; m.wd = e->L[i].wd; m.biasp = e->L[i].biasp;
             }
-        }
-        int rc = orn_merge_groups_build(e->merge_tables, d->n_layers, ml, d->precision != 0);
-        if (rc == 0 && d->precision != 0) {
+        };
+        // set 0: every layer; set 1: all but the last block (caller's stream of the pipelined step); set 2: the last block (side stream)
+        const int nl = d->n_layers;
+        for (int k = 0; k < (e->pipe_ok ? 3 : 1); ++k) {
+            orn_engine::MergeSet &ms = e->mset[k];
+            const int i0 = k == 2 ? nl - 1 : 0, i1 = k == 1 ? nl - 1 : nl;
+            ms.n = 0;
             void *bufs[ORN_MAX_LAYERS];
-            for (int i = 0; i < d->n_layers; ++i) bufs[i] = e->L[i].mh16;
-            e->mh_host = malloc(orn_merge_h16_host_bytes());
-            rc = e->mh_host ? orn_merge_h16_build(e->mh_tables, e->mh_host, d->n_layers, ml, bufs, e->sc) : ORN_E_ARG;
+            for (int i = i0; i < i1; ++i) {
+                fill(i, ms.ml[ms.n], k == 2 || !e->stage0);
+                bufs[ms.n] = e->L[i].mh16;
+                ms.layer[ms.n++] = i;
+            }
+            int rc = orn_merge_groups_build(ms.tables, ms.n, ms.ml, d->precision != 0);
+            if (rc == 0 && d->precision != 0) {
+                ms.mh_host = malloc(orn_merge_h16_host_bytes());
+                rc = ms.mh_host ? orn_merge_h16_build(ms.mh_tables, ms.mh_host, ms.n, ms.ml, bufs, k == 2 ? e->sc_side : e->sc) : ORN_E_ARG;
+            }
+            if (rc != 0) { orn_engine_destroy(e); return rc; }
+            for (int q = 0; q < 4; ++q) ms.tiles[q] = orn_merge_group_tiles(q, ms.n, ms.ml);
         }
-        if (rc != 0) { free(e->mh_host); delete e; return rc; }
-        for (int k = 0; k < 4; ++k) e->merge_tiles[k] = orn_merge_group_tiles(k, d->n_layers, ml);
     }
     *out = e;
     return 0;
@@ -297,7 +368,10 @@ extern "C" void orn_engine_destroy(orn_engine *e)
     if (e->graph_u) (void)hipGraphDestroy(e->graph_u);
     for (int i = 0; i < 4 * ORN_MAX_LAYERS + 4; ++i)
         if (e->prof_ev[i]) (void)hipEventDestroy(e->prof_ev[i]);
-    free(e->mh_host);
+    if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
+    hipEvent_t evs[4] = {e->ev_fork, e->ev_adam, e->ev_wgrad, e->ev_join};
+    for (int k = 0; k < 4; ++k) if (evs[k]) (void)hipEventDestroy(evs[k]);
+    for (int k = 0; k < 3; ++k) free(e->mset[k].mh_host);
     delete e;
 }
 
@@ -418,12 +492,14 @@ __global__ void k_advance(const orn_step_sched *__restrict__ sched, int32_t *cur
 // forward needs no stored activation either
 static bool f32_head_on_z(const orn_engine *e)
 {
-    static const bool no_head_fuse = getenv("ORN_F32_HEAD_UNFUSED") != nullptr;       // tools/probes A/B
+    static const bool no_head_fuse = orn_probe_env("ORN_F32_HEAD_UNFUSED") != nullptr;       // tools/probes A/B
     const orn_engine_desc &d = e->d;
     return e->ff >= d.n_layers && e->head_ws && d.layer[d.n_layers - 1].s == 2 && !no_head_fuse;
 }
 
-static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool keep_z, hipStream_t st)
+// set: which layers this forward merges (0 all; 1: all but the last block, whose merged kernel the side branch of the previous
+// pipelined step leaves behind -- the forward then waits for that branch where it touches the last block's buffers)
+static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool keep_z, hipStream_t st, int set = 0)
 {
     const orn_engine_desc &d = e->d;
     const int Nout = d.fc_h * d.fc_w * d.fc_dim;
@@ -440,11 +516,12 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
         // the stem's two linear layers as extra work-groups
         // half operand copies for the merge BACKWARD (training step, 16-bit modes) as riders: the parameter-side ones behind
         // the W2 transposes, T -> Th behind the first block's launch (or, without it, behind the S products)
+        const orn_engine::MergeSet &ms = e->mset[set];
         int pk_par = 0, pk_t = 0;
-        const void *pk = (keep_z && e->mh_host) ? orn_merge_h16_pack(e->mh_host, &pk_par, &pk_t) : nullptr;
-        ORN_TRY(orn_launch_w2_transpose(nl, e->ml, st, pk, pk_par));
-        ORN_TRY(orn_launch_merge_group_linear(e->merge_tables, 0, e->merge_tiles[0], lin1, st));
-        ORN_TRY(orn_launch_merge_group_linear(e->merge_tables, 1, e->merge_tiles[1], lin2, st, e->stage0 ? nullptr : pk, e->stage0 ? 0 : pk_t));
+        const void *pk = (keep_z && ms.mh_host) ? orn_merge_h16_pack(ms.mh_host, &pk_par, &pk_t) : nullptr;
+        ORN_TRY(orn_launch_w2_transpose(ms.n, ms.ml, st, pk, pk_par));
+        ORN_TRY(orn_launch_merge_group_linear(ms.tables, 0, ms.tiles[0], lin1, st));
+        ORN_TRY(orn_launch_merge_group_linear(ms.tables, 1, ms.tiles[1], lin2, st, e->stage0 ? nullptr : pk, e->stage0 ? 0 : pk_t));
         pack_t = e->stage0 ? pk : nullptr; pack_t_blocks = e->stage0 ? pk_t : 0;
     } else {
         ORN_TRY(orn_launch_linear_silu(lin1.x, lin1.row_idx, lin1.row_stride, lin1.w, lin1.bias, 1, lin1.K, lin1.N, lin1.pre, lin1.y, st));
@@ -452,11 +529,12 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
     }
     if (ff < nl && !d.erb) {      // 16-bit operand copies of every fast layer's kernel, one launch (ERB: written by the merge's S launch)
         OrnPrepLayer pl[ORN_MAX_LAYERS];
-        for (int i = ff; i < nl; ++i) {
+        const int np = (set == 1 ? nl - 1 : nl) - ff;       // (pipelined step: the side branch prepares the last block's)
+        for (int i = ff; i < ff + np; ++i) {
             const orn_layer_desc &l = d.layer[i];
             pl[i - ff] = OrnPrepLayer{e->L[i].wf, e->L[i].bf, l.O, l.C, l.s, e->L[i].wb, e->L[i].wd, e->L[i].biasp, ORN_FAST_C};
         }
-        ORN_TRY(e->ops->prep_all(nl - ff, pl, st));
+        ORN_TRY(e->ops->prep_all(np, pl, st));
     }
     OrnHeadFuse hf = {};
     for (int i = 0; i < nl; ++i) {
@@ -469,7 +547,7 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
                 OrnPrepLayer pl[ORN_MAX_LAYERS];
                 int np = 0;
                 if (d.erb)
-                    for (int j = ff; j < nl; ++j) {
+                    for (int j = ff; j < (set == 1 ? nl - 1 : nl); ++j) {
                         const orn_layer_desc &lj = d.layer[j];
                         pl[np++] = OrnPrepLayer{e->L[j].wf, e->L[j].bf, lj.O, lj.C, lj.s, e->L[j].wb, e->L[j].wd, e->L[j].biasp, ORN_FAST_C};
                     }
@@ -490,6 +568,10 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
             if (e->prof) (void)hipEventRecord(e->prof_ev[2 * i], st);
             // the last block's kernel may run the head in its epilogue (it then holds every channel of an output pixel)
             const bool last = (i + 1 == nl);
+            // pipelined step: the side branch of the previous step still reads the last block's input buffer (its weight gradient)
+            // until ev_wgrad, and writes that block's merged kernel (and the head's parameters) until ev_join
+            if (e->side_busy && i + 2 == nl) ORN_HIP(hipStreamWaitEvent(st, e->ev_wgrad, 0));
+            if (e->side_busy && last) { ORN_HIP(hipStreamWaitEvent(st, e->ev_join, 0)); e->side_busy = false; }
             if (last) hf = OrnHeadFuse{P + d.head_w, P + d.head_b, e->img, d.sigmoid, 0};
             ORN_TRY(e->ops->conv_fwd(b.xpad, b.wb, b.biasp, l.H, l.W, ORN_FAST_C, l.O, l.s, b.zb, last ? nullptr : e->L[i + 1].xpad, st, l.C,
                                      last ? &hf : nullptr));
@@ -520,8 +602,89 @@ extern "C" int orn_engine_decode(orn_engine *e, const float *embed, float *img, 
 
 // adv_count > 0: advance the device-side schedule by that many steps first (states e->cur[0 .. adv_count)); the step itself
 // runs on e->cur[cur_idx]
+static OrnMergeMisc merge_misc(const orn_engine *e, int i)
+{
+    const orn_layer_desc &l = e->d.layer[i];
+    float *G = e->grads;
+    OrnMergeMisc m = {};
+    m.C = l.C; m.O = l.O;
+    m.g = G + l.w3x3; m.dbf = G + l.b3x3; m.dw1p = e->L[i].dw1p;
+    m.d3x1 = G + l.w3x1; m.db3x1 = G + l.b3x1; m.d1x3 = G + l.w1x3; m.db1x3 = G + l.b1x3;
+    m.dw1 = G + l.w1;
+    if (e->d.precision != 0) { m.dw2t = e->L[i].dw2t; m.dw2 = G + l.w2; }
+    return m;
+}
+
+// Split-K slabs of the LAST block's weight gradient on an engine that can run the pipelined step: fewer, longer work-groups (one
+// per CU or less) leave room on every CU for the launches that run beside it.  Measured on the 720p step (tools/probes, round 4):
+// 40 / 24 / 16 slabs = 1.068 / 1.028 / 1.034 ms per pipelined step.  The serial forms of the step use the same count, so that all
+// forms of the step give bit-identical results.
+static int last_smax(const orn_engine *e)
+{
+    static const int smax = orn_probe_env_int("ORN_SIDE_SMAX", 24);
+    return e->pipe_ok ? smax : 0;
+}
+
+// The side branch of a pipelined step, first half (enqueued where the caller's stream has finished the dgrad chain and the lower
+// blocks' weight gradients): the last block's weight gradient (+ the head's dW / db finish), its slab reduction, its merge backward.
+static int side_branch_backward(orn_engine *e, hipStream_t st)
+{
+    const orn_engine_desc &d = e->d;
+    const int nl = d.n_layers;
+    const orn_layer_desc &l = d.layer[nl - 1];
+    float *G = e->grads;
+    hipStream_t sd = e->side;
+    OrnScaleState *sc = e->sc_side;                     // this step's scale, copied by the loss's finalize stage; late detections
+    ORN_HIP(hipEventRecord(e->ev_fork, st));
+    ORN_HIP(hipStreamWaitEvent(sd, e->ev_fork, 0));
+    const OrnWgradJob wj = {e->L[nl - 1].xpad, e->L[nl - 1].dypad, l.H, l.W, l.C, l.O, l.s, e->L[nl - 1].wslab, last_smax(e)};
+    const OrnHeadFinish hf = {e->head_ws, e->ops->head_bwd_blocks(e->Hout, e->Wout), e->Cn_last, 1.0f / e->gs, G + d.head_w, G + d.head_b, sc};
+    ORN_TRY(e->ops->wgrad_batch(1, &wj, sd, &hf, nullptr));
+    ORN_HIP(hipEventRecord(e->ev_wgrad, sd));           // the last block's input buffer is free again
+    const OrnWgradReduce wr = {e->L[nl - 1].wslab, l.H, l.W, l.C, l.O, l.s, 1.0f / e->gs, G + l.w3x3, G + l.b3x3, sc, last_smax(e)};
+    ORN_TRY(e->ops->wgrad_reduce_all(1, &wr, sd, nullptr));
+    if (d.erb) {
+        const orn_engine::MergeSet &ms = e->mset[2];
+        ORN_TRY(orn_launch_merge_h16_bwd(ms.mh_tables, ms.mh_host, sd, sc));
+        const OrnMergeMisc mm = merge_misc(e, nl - 1);
+        ORN_TRY(orn_launch_merge_bwd_tail_all(1, &mm, sd));
+    }
+    return 0;
+}
+
+// Second half (enqueued behind the caller's Adam launch, whose skip decision it follows): Adam over the last block's and the head's
+// parameters, then the last block's merge forward (or, without ERB, its 16-bit operand copies) for the NEXT step.
+static int side_branch_update(orn_engine *e)
+{
+    const orn_engine_desc &d = e->d;
+    const int nl = d.n_layers;
+    hipStream_t sd = e->side;
+    const size_t lo = e->side_lo;
+    ORN_HIP(hipStreamWaitEvent(sd, e->ev_adam, 0));
+    ORN_TRY(orn_launch_adam(e->params + lo, e->grads + lo, e->m + lo, e->v + lo, (size_t)d.n_params - lo, 0.0, 1, e->cur_side, d.beta1, d.beta2,
+                            d.eps, 1.0f, sd, e->gmask ? e->gmask + lo : nullptr, e->sc_side, nullptr, nullptr, false));
+    if (d.erb) {
+        const orn_engine::MergeSet &ms = e->mset[2];
+        int pk_par = 0, pk_t = 0;
+        const void *pk = ms.mh_host ? orn_merge_h16_pack(ms.mh_host, &pk_par, &pk_t) : nullptr;
+        const OrnLinearJob none = {};
+        ORN_TRY(orn_launch_w2_transpose(ms.n, ms.ml, sd, pk, pk_par));
+        ORN_TRY(orn_launch_merge_group_linear(ms.tables, 0, ms.tiles[0], none, sd));
+        ORN_TRY(orn_launch_merge_group_linear(ms.tables, 1, ms.tiles[1], none, sd, pk, pk_t));   // the S epilogue writes the 16-bit operand copies
+    } else {
+        const orn_layer_desc &l = d.layer[nl - 1];
+        const OrnPrepLayer pl = {e->L[nl - 1].wf, e->L[nl - 1].bf, l.O, l.C, l.s, e->L[nl - 1].wb, e->L[nl - 1].wd, e->L[nl - 1].biasp, ORN_FAST_C};
+        ORN_TRY(e->ops->prep_all(1, &pl, sd));
+    }
+    ORN_HIP(hipEventRecord(e->ev_join, sd));
+    e->side_busy = true;
+    return 0;
+}
+
+// pipe: the pipelined form (struct orn_engine, `side`): the last block's weight-gradient chain leaves this step on the side stream
 static int train_step(orn_engine *e, const float *frames, const float *embeds, const orn_step_sched *sched,
-                      int32_t *cursor, float *stats_out, int32_t n_slots, hipStream_t st, int adv_count = 1, int cur_idx = 0)
+                      int32_t *cursor, float *stats_out, int32_t n_slots, hipStream_t st, int adv_count = 1, int cur_idx = 0,
+                      bool pipe = false)
 {
     const orn_engine_desc &d = e->d;
     float *P = e->params, *G = e->grads;
@@ -534,12 +697,13 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
     }
     OrnScaleState *const sc = e->sc + cur_idx;          // this step's entry: its own flag, the shared scale
     const int *fidx = &cur->frame;
-    ORN_TRY(forward(e, embeds, fidx, true, st));
+    ORN_TRY(forward(e, embeds, fidx, true, st, (pipe && e->side_busy) ? 1 : 0));
     const int nl = d.n_layers, ff = e->ff;
     OrnLossFinalJob fin = {};
     ORN_TRY(orn_launch_loss(e->img, frames, fidx, 3 * HWo, 1, 3, e->Hout, e->Wout, d.loss_type, 1.0f, e->stats, e->dimg,
                             e->loss_ws, st, cur, stats_out, sc, d.loss_type == ORN_LOSS_FUSION6 ? e->tstats : nullptr,
                             ff < nl ? &fin : nullptr));     // 16-bit engine: the finalize stage rides on the head's backward launch
+    if (pipe) { fin.cur_copy = e->cur_side; fin.sc_copy = e->sc_side; }     // (the previous step's side branch was joined in forward())
     if (ff < nl)
         ORN_TRY(e->ops->head_bwd(e->L[nl - 1].zb, P + d.head_w, e->img, e->dimg, e->Cn_last, e->Hout, e->Wout, d.sigmoid,
                                  d.layer[nl - 1].s, e->gs, e->L[nl - 1].dypad, nullptr, nullptr, e->head_ws, st, sc, &fin));   // dW / db: finished with the wgrad batch
@@ -554,7 +718,6 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         for (int i = 0; i < nl; ++i) { wfs[i] = e->L[i].wf; wds[i] = e->L[i].wd32; Os[i] = d.layer[i].O; Cs[i] = d.layer[i].C; }
         ORN_TRY(orn_launch_flip_transpose_all(nl, wfs, wds, Os, Cs, st));
     }
-    int wgrad_rode[ORN_MAX_LAYERS] = {};
     for (int i = nl - 1; i >= 0; --i) {
         const orn_layer_desc &l = d.layer[i];
         LayerBuf &b = e->L[i];
@@ -567,12 +730,10 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
             if (i > ff) {
                 // few pixel tiles: input-chunk split through fp32 partial slabs in the scratch, finished into dypad
                 float *part = e->ops->dgrad_f32_slabs(l.H, l.W, l.O) > 1 ? e->scratch : nullptr;
-                // (the block's own wgrad rides behind the dgrad tiles where the launch can carry it: wgrad_rode[i])
-                const OrnWgradJob wjob = {b.xpad, b.dypad, l.H, l.W, l.C, l.O, l.s, b.wslab};
                 ORN_TRY(e->ops->conv_dgrad(b.dypad, b.wd, l.H, l.W, l.O, l.C, e->L[i - 1].zb, e->L[i - 1].dypad, d.layer[i - 1].s,
-                                           part, st, l.C, &wjob, &wgrad_rode[i]));
+                                           part, st, l.C));
             } else {
-                ORN_TRY(e->ops->conv_dgrad(b.dypad, b.wd, l.H, l.W, l.O, ORN_FAST_C, nullptr, nullptr, 1, e->dxn, st, l.C, nullptr, nullptr));
+                ORN_TRY(e->ops->conv_dgrad(b.dypad, b.wd, l.H, l.W, l.O, ORN_FAST_C, nullptr, nullptr, 1, e->dxn, st, l.C));
                 if (!e->stage0)
                 ORN_TRY(e->ops->to_nchw_f32(e->dxn, l.C, ORN_FAST_C, l.H, l.W, e->ops->dgrad_f32_slabs(l.H, l.W, l.O), 1.0f / e->gs, dx,
                                             st, sc));
@@ -600,42 +761,43 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         // at a time: -37 us per 720p step), followed by ONE launch that reduces every layer's split-K slabs (-27 us).
         OrnWgradJob wj[ORN_MAX_LAYERS];
         int nj = 0;
-        for (int i = nl - 1; i >= ff; --i) {        // largest first; blocks whose wgrad rode on their dgrad launch are done
+        const int n_main = pipe ? nl - 1 : nl;      // (pipelined step: the last block's is the side branch's)
+        for (int i = n_main - 1; i >= ff; --i) {    // largest first
             const orn_layer_desc &l = d.layer[i];
-            if (!wgrad_rode[i]) wj[nj++] = OrnWgradJob{e->L[i].xpad, e->L[i].dypad, l.H, l.W, l.C, l.O, l.s, e->L[i].wslab};
+            wj[nj++] = OrnWgradJob{e->L[i].xpad, e->L[i].dypad, l.H, l.W, l.C, l.O, l.s, e->L[i].wslab, (i == nl - 1) ? last_smax(e) : 0};
         }
         const OrnHeadFinish hf = {e->head_ws, e->ops->head_bwd_blocks(e->Hout, e->Wout), e->Cn_last, 1.0f / e->gs, G + d.head_w, G + d.head_b, sc};
         if (e->prof) (void)hipEventRecord(e->prof_ev[4 * ORN_MAX_LAYERS], st);
-        ORN_TRY(e->ops->wgrad_batch(nj, wj, st, &hf, &l2job));
+        ORN_TRY(e->ops->wgrad_batch(nj, wj, st, pipe ? nullptr : &hf, &l2job));
         if (e->prof) (void)hipEventRecord(e->prof_ev[4 * ORN_MAX_LAYERS + 1], st);
         OrnWgradReduce wr[ORN_MAX_LAYERS];
-        for (int i = ff; i < nl; ++i) {
+        for (int i = ff; i < n_main; ++i) {
             const orn_layer_desc &l = d.layer[i];
-            wr[i - ff] = OrnWgradReduce{e->L[i].wslab, l.H, l.W, l.C, l.O, l.s, 1.0f / e->gs, G + l.w3x3, G + l.b3x3, sc};
+            wr[i - ff] = OrnWgradReduce{e->L[i].wslab, l.H, l.W, l.C, l.O, l.s, 1.0f / e->gs, G + l.w3x3, G + l.b3x3, sc, (i == nl - 1) ? last_smax(e) : 0};
         }
         if (e->prof) (void)hipEventRecord(e->prof_ev[4 * ORN_MAX_LAYERS + 2], st);
-        ORN_TRY(e->ops->wgrad_reduce_all(nl - ff, wr, st, &w0job));
+        ORN_TRY(e->ops->wgrad_reduce_all(n_main - ff, wr, st, &w0job));
         if (e->prof) (void)hipEventRecord(e->prof_ev[4 * ORN_MAX_LAYERS + 3], st);
     }
+    if (pipe) ORN_TRY(side_branch_backward(e, st));     // fork: the last block's wgrad .. merge backward, on the side stream
     if (d.erb) {
         // merge backward of every layer (closed forms): dW3 & dT, then dW2 & dW1, then the slices
+        const orn_engine::MergeSet &ms = e->mset[pipe ? 1 : 0];
         if (d.precision != 0) {
-            ORN_TRY(orn_launch_merge_h16_bwd(e->mh_tables, e->mh_host, st, sc));
+            ORN_TRY(orn_launch_merge_h16_bwd(ms.mh_tables, ms.mh_host, st, sc));
         } else {
-            ORN_TRY(orn_launch_merge_group(e->merge_tables, 2, e->merge_tiles[2], st));
-            ORN_TRY(orn_launch_merge_group(e->merge_tables, 3, e->merge_tiles[3], st));
+            ORN_TRY(orn_launch_merge_group(ms.tables, 2, ms.tiles[2], st));
+            ORN_TRY(orn_launch_merge_group(ms.tables, 3, ms.tiles[3], st));
         }
         OrnMergeMisc mm[ORN_MAX_LAYERS];
-        for (int i = 0; i < nl; ++i) {
-            const orn_layer_desc &l = d.layer[i];
-            mm[i] = OrnMergeMisc{};
-            mm[i].C = l.C; mm[i].O = l.O;
-            mm[i].g = G + l.w3x3; mm[i].dbf = G + l.b3x3; mm[i].dw1p = e->L[i].dw1p;
-            mm[i].d3x1 = G + l.w3x1; mm[i].db3x1 = G + l.b3x1; mm[i].d1x3 = G + l.w1x3; mm[i].db1x3 = G + l.b1x3;
-            mm[i].dw1 = G + l.w1;
-            if (d.precision != 0) { mm[i].dw2t = e->L[i].dw2t; mm[i].dw2 = G + l.w2; }
-        }
-        ORN_TRY(orn_launch_merge_bwd_tail_all(nl, mm, st));
+        for (int k = 0; k < ms.n; ++k) mm[k] = merge_misc(e, ms.layer[k]);
+        ORN_TRY(orn_launch_merge_bwd_tail_all(ms.n, mm, st));
+    }
+    if (pipe) {
+        // this stream's Adam launch covers everything below the last block; its skip decision is mirrored for the side branch's launch
+        ORN_TRY(orn_launch_adam(P, G, e->m, e->v, e->side_lo, 0.0, 1, cur, d.beta1, d.beta2, d.eps, 1.0f, st, e->gmask, sc, e->sc, e->sc_side));
+        ORN_HIP(hipEventRecord(e->ev_adam, st));
+        return side_branch_update(e);
     }
     ORN_TRY(orn_launch_adam(P, G, e->m, e->v, (size_t)d.n_params, 0.0, 1, cur, d.beta1, d.beta2, d.eps, 1.0f, st, e->gmask, sc, e->sc));
     return 0;
@@ -648,6 +810,25 @@ extern "C" int orn_engine_train_step(orn_engine *e, const float *frames, const f
     ORN_REQUIRE(e && frames && embeds && sched && cursor, "engine_train_step: null pointer");
     ORN_REQUIRE(e->grads && e->m && e->v, "engine_train_step: engine was created without grads / Adam arenas");
     return train_step(e, frames, embeds, sched, cursor, stats_out, n_slots, (hipStream_t)stream);
+}
+
+// n_steps steps enqueued on `stream` (no graph): where the engine can (struct orn_engine, `side`) in the pipelined form, the
+// last block's weight-gradient chain of step k running on the engine's own second stream beside the boundary of steps k / k + 1.
+// Everything is joined back into `stream` before the call returns, so the caller's stream order covers all of it.
+extern "C" int orn_engine_train_steps(orn_engine *e, const float *frames, const float *embeds, const orn_step_sched *sched,
+                                      int32_t *cursor, float *stats_out, int32_t n_slots, int32_t n_steps, void *stream)
+{
+    ORN_REQUIRE(e && frames && embeds && sched && cursor && n_steps >= 0, "engine_train_steps: bad arguments");
+    ORN_REQUIRE(e->grads && e->m && e->v, "engine_train_steps: engine was created without grads / Adam arenas");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = 0;
+    for (int k = 0; k < n_steps && rc == 0; ++k) rc = train_step(e, frames, embeds, sched, cursor, stats_out, n_slots, st, 1, 0, e->pipe_ok);
+    if (e->side_busy) {
+        const hipError_t hrc = hipStreamWaitEvent(st, e->ev_join, 0);
+        e->side_busy = false;
+        if (hrc != hipSuccess && rc == 0) { orn_set_error("engine_train_steps: join: %s", hipGetErrorString(hrc)); rc = (int)hrc; }
+    }
+    return rc;
 }
 
 // One EAGER training step with HIP events around every layer's forward conv launch, on the launch stream:
@@ -725,7 +906,7 @@ extern "C" int orn_engine_train_steps_graph(orn_engine *e, const float *frames, 
     // The host needs longer to launch the unrolled graph than the single-step one, and on an idle stream that launch is exposed (the
     // device waits for it): a call that will launch several graphs starts with ONE single step, and the unrolled launches queue up
     // behind it while it runs.  (20-step timed region after a synchronise: see DESIGN 6.)
-    static const bool first_single = getenv("ORN_GRAPH_NO_FIRST_SINGLE") == nullptr;
+    static const bool first_single = orn_probe_env("ORN_GRAPH_NO_FIRST_SINGLE") == nullptr;
     if (first_single && left > ORN_GRAPH_UNROLL) {
         hipError_t rc = hipGraphLaunch(e->graph_exec, st);
         if (rc != hipSuccess) { orn_set_error("graph: Launch failed: %s", hipGetErrorString(rc)); return (int)rc; }

@@ -19,7 +19,9 @@ int orn_launch_head_bwd(const float *a, const float *w, const float *out, const 
 int orn_launch_adam(float *p, const float *g, float *m, float *v, size_t n, double lr, int step, const OrnStepCur *sp,
                     double beta1, double beta2, double eps, float inv_gscale, hipStream_t st, const float *gmask = nullptr,
                     OrnScaleState *sc = nullptr,    // sc: skip the update while its flag is up
-                    OrnScaleState *sc_master = nullptr);   // (engine: the entry that counts skipped steps; default sc itself)
+                    OrnScaleState *sc_master = nullptr,    // (engine: the entry that counts skipped steps; default sc itself)
+                    OrnScaleState *mirror = nullptr,       // (engine, deferred last block) the skip decision is also stored into mirror->flag
+                    bool count_skip = true);               // false: a skipped launch does not count (the step's other Adam launch does)
 
 // orn_stage0.hip: the fp32 block below the first 16-bit one (tiny stem image), forward / backward as one launch each
 bool orn_stage0_supported(int C, int O, int H, int W, int s);
@@ -112,10 +114,10 @@ int orn_launch_loss(const float *pred, const float *target, const int *frame_idx
 // twice (bf16 and, with -DORN_FP16, IEEE half); the engine reaches either build through this type-erased table.
 struct OrnPrepLayer { const float *wf, *bf; int O, C, s; void *wb, *wd; float *biasp; int Cp; };   // Cp: channel stride (0: = C)
 // deferred split-K reduction of a layer's wgrad slabs (wgrad called with dwf == nullptr leaves them in `slabs`)
-struct OrnWgradReduce { const float *slabs; int H, W, C, O, s; float gscale; float *dwf, *dbf; OrnScaleState *sc; };   // sc (optional): 1/scale from the device state, non-finite results raise its flag
+struct OrnWgradReduce { const float *slabs; int H, W, C, O, s; float gscale; float *dwf, *dbf; OrnScaleState *sc; int smax; };   // sc (optional): 1/scale from the device state, non-finite results raise its flag
 // deferred reduction of the 16-bit head backward's per-block partials (head_bwd called with dw == nullptr leaves them in ws)
 struct OrnHeadFinish { const float *partial; int blocks, C; float gscale; float *dw, *db; OrnScaleState *sc; };
-struct OrnWgradJob { const void *xpad, *dypad; int H, W, C, O, s; float *slabs; };   // wgrad into slabs, reduction deferred
+struct OrnWgradJob { const void *xpad, *dypad; int H, W, C, O, s; float *slabs; int smax; };   // wgrad into slabs, reduction deferred; smax > 0: at most that many split-K slabs (the reduction must be told the same)
 // A5 head riding on the last block's forward (its epilogue holds all channels of an output pixel): out = act(W SiLU(z) + b).
 // The launcher sets `fused` when the kernel it chose did the head; otherwise the caller launches head_fwd on z.
 struct OrnHeadFuse { const float *w, *b; float *out; int sigmoid; int fused; };
@@ -123,8 +125,7 @@ struct OrnHalfOps {
     int (*conv_fwd)(const void *xpad, const void *wb, const float *bias_p, int H, int W, int Cin, int O, int s, void *z, void *apad,
                     hipStream_t st, int c_real, OrnHeadFuse *head);   // c_real <= Cin: input channels that are not zero padding; head: optional
     int (*conv_dgrad)(const void *dypad, const void *wd, int H, int W, int O, int C, const void *zprev, void *dyprev, int sp,
-                      float *dx_f32, hipStream_t st, int c_real,   // c_real: output channels that are not zero padding
-                      const OrnWgradJob *wgrad, int *wgrad_done);   // wgrad (optional): the block's own wgrad job; *wgrad_done = 1 when this launch carried it
+                      float *dx_f32, hipStream_t st, int c_real);   // c_real: output channels that are not zero padding
     size_t (*wgrad_ws_floats)(int H, int W, int O);
     int (*wgrad)(const void *xpad, const void *dypad, int H, int W, int C, int O, int s, float gscale, float *slabs, float *dwf,
                  float *dbf, hipStream_t st);

@@ -593,7 +593,7 @@ static void finish_gemm(GemmP &p)
 static int launch_gemm(GemmP p, int batch, hipStream_t st, const char *name)
 {
     finish_gemm(p);
-    static const bool old_body = getenv("ORN_MERGE_OLD_BODY") != nullptr;      // probe switch (tools/probes/merge_probe.py)
+    static const bool old_body = orn_probe_env("ORN_MERGE_OLD_BODY") != nullptr;      // probe switch (tools/probes/merge_probe.py)
     if (p.sbn == 1 && !old_body) hipLaunchKernelGGL(k_gemm2_f32, dim3(orn_cdiv(p.N, GT), orn_cdiv(p.M, GT), batch), dim3(256), 0, st, p);
     else
     hipLaunchKernelGGL(k_gemm_f32, dim3(orn_cdiv(p.N, GT), orn_cdiv(p.M, GT), batch), dim3(256), 0, st, p);
@@ -951,7 +951,11 @@ int orn_launch_merge_group_linear(const void *dev_tables, int which, int tiles, 
     const size_t smem = G2_LDS_BYTES(which == 0 ? 1 : 0) > 64 * 65 * 4 ? G2_LDS_BYTES(which == 0 ? 1 : 0) : 64 * 65 * 4;
     MhPackAll pk = {};
     if (pack && pack_blocks > 0) pk = *(const MhPackAll *)pack; else pack_blocks = 0;
-    static const int dbg = getenv("ORN_MERGE_DBG") ? atoi(getenv("ORN_MERGE_DBG")) : 0;      // probe switch: timing only, results WRONG
+#ifdef ORN_PROBE_BUILD      // diagnostic builds only (ORN_BUILD_TAG + ORN_EXTRA_DEFS=-DORN_PROBE_BUILD): timing switch, results WRONG
+    static const int dbg = orn_probe_env_int("ORN_MERGE_DBG", 0);
+#else
+    constexpr int dbg = 0;
+#endif
     if (dbg & 1) pack_blocks = 0;
     if (dbg & 2) lin_blocks = 0;
     if (dbg & 4) {                                    // one launch per problem: their durations inside a real step (rocprofv3 timeline)

@@ -179,14 +179,21 @@ class TrainEngine:
         self._sched_len = arr.shape[0]
 
     # ---- stepping -----------------------------------------------------------------------------
-    def run(self, n_steps: int, graph: bool = True):
-        """Enqueue `n_steps` optimiser steps consuming the uploaded schedule (no host sync)."""
+    def run(self, n_steps: int, graph=None):
+        """Enqueue `n_steps` optimiser steps consuming the uploaded schedule (no host sync).
+        graph=None (default): orn_engine_train_steps -- plain stream launches, pipelined over the engine's second stream where the
+        engine can (16-bit modes; include/orn.h); graph=True: hipGraph replay of the serial step; graph=False: one
+        orn_engine_train_step call per step.  All three give bit-identical results."""
         if self.frames is None or self.sched is None:
             raise OrnError('set_video() and set_schedule() first')
         cur = torch.cuda.current_stream()
         self.stream.wait_stream(cur)
         st = c_void_p(self.stream.cuda_stream)
-        if graph:
+        if graph is None:
+            check(lib().orn_engine_train_steps(self._h, _lib.ptr(self.frames), _lib.ptr(self.embeds), _lib.ptr(self.sched),
+                                               _lib.ptr(self.cursor), _lib.ptr(self.stats_ring), c_int32(self.n_slots),
+                                               c_int32(n_steps), st), 'orn_engine_train_steps')
+        elif graph:
             check(lib().orn_engine_train_steps_graph(self._h, _lib.ptr(self.frames), _lib.ptr(self.embeds), _lib.ptr(self.sched),
                                                      _lib.ptr(self.cursor), _lib.ptr(self.stats_ring), c_int32(self.n_slots),
                                                      c_int32(n_steps), st), 'orn_engine_train_steps_graph')

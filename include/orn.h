@@ -238,6 +238,14 @@ ORN_API int orn_engine_set_target_stats(orn_engine *e, const float *stats);
  * reference counterpart. */
 ORN_API int orn_engine_profile_step(orn_engine *e, const float *frames, const float *embeds, const orn_step_sched *sched,
                             int32_t *cursor, float *stats_out, int32_t n_slots, float *ms_out, void *stream);
+/* n_steps optimiser steps enqueued on `stream` without a graph (main_train.py:229-254, the loop body n times).  Engines in a
+ * 16-bit mode with at least two blocks on the fast path run them PIPELINED: the last block's weight gradient, its slab reduction,
+ * merge backward, Adam update (with the head's) and next merge forward run on a second stream the engine owns, forked off at the end
+ * of the backward and joined in front of that block's forward conv of the next step, so that this chain overlaps the latency-bound
+ * launches of the step boundary.  Same arithmetic, same order of every sum: bit-identical to orn_engine_train_step.  All work is
+ * joined back into `stream` before the call returns (stream order on `stream` covers it). */
+ORN_API int orn_engine_train_steps(orn_engine *e, const float *frames, const float *embeds, const orn_step_sched *sched,
+                           int32_t *cursor, float *stats_out, int32_t n_slots, int32_t n_steps, void *stream);
 /* Capture one train step into a hipGraph on `stream` and replay it n times (same arguments as above). */
 ORN_API int orn_engine_train_steps_graph(orn_engine *e, const float *frames, const float *embeds,
                                  const orn_step_sched *sched, int32_t *cursor, float *stats_out,
