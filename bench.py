@@ -293,6 +293,7 @@ def timed_leg(eng, steps, warmup, graph, dist, device_sync):
     import torch
     eng.set_schedule(schedule(warmup + steps))
     eng.run(warmup, graph=graph)
+    p0 = eng.params.clone() if hasattr(eng, 'params') else None     # (witness below; outside the timed region)
     device_sync()
     if dist:
         dist.barrier()
@@ -309,6 +310,9 @@ def timed_leg(eng, steps, warmup, graph, dist, device_sync):
         t = torch.tensor([dt], dtype=torch.float64, device='cuda' if torch.cuda.is_available() and dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if p0 is not None:     # liveness witness of the timed steps (after the clock has stopped): how far they moved the parameters
+        eng.last_param_delta_l2 = float((eng.params.double() - p0.double()).norm())
+        del p0
     return dt, own, eng.stats(warmup + steps)
 
 
@@ -357,6 +361,10 @@ def worker(args):
                        'launch_mode': 'eager' if args.no_graph else args.mode,
                        'timed_region': 'optimiser steps incl. loss, backward, Adam, per-step PSNR; MS-SSIM logging excluded, checkpoint I/O excluded',
                        'train_psnr_mean_timed_steps': psnr_last, 'finite': ok,
+                       # witnesses that the timed steps trained (they differ between precisions and builds): loss of the last timed step,
+                       # L2 norm of (parameters after - before the timed region), Adam's step count as the device wrote it into the ring
+                       'last_timed_step_loss': float(stats[-1, 0]), 'last_timed_step_adam_count': int(stats[-1, 7]),
+                       'param_delta_l2_timed_steps': getattr(eng, 'last_param_delta_l2', None),
                        'whole_step_tflops': world * args.steps / dt * cfg['flop_step'] / 1e12},
             'rccl_ranks': (dist.get_world_size() if dist else 1), 'per_rank_frames_per_s': per_rank,
         }
@@ -418,6 +426,8 @@ def worker(args):
                 out['fp32'] = {
                     'value': s32 / dt32, 'unit': 'frames/s', 'steps': s32, 'warmup': w32, 'ms_per_step': dt32 / s32 * 1e3, 'dtype': 'f32',
                     'finite': bool(torch.isfinite(st32[:, 0]).all()), 'train_psnr_mean_timed_steps': float(st32[w32:, 4].mean()),
+                    'last_timed_step_loss': float(st32[-1, 0]), 'last_timed_step_adam_count': int(st32[-1, 7]),
+                    'param_delta_l2_timed_steps': getattr(e32, 'last_param_delta_l2', None),
                     'whole_step_tflops': s32 / dt32 * cfg['flop_step'] / 1e12,
                     'roofline': {'bound': 'mfma', 'achieved': d32['tflops'], 'peak': PEAK['fp32'], 'unit': 'TFLOP/s', 'frac': d32['frac'],
                                  'kernel': d32['kernel'], 'kernels': k32,

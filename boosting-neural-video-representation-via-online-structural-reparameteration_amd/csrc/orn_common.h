@@ -49,6 +49,10 @@ int orn_probe_env_int(const char *name, int dflt);
         if (rc__ != 0) return rc__;   \
     } while (0)
 
+// Wave priority of the kernels on the caller's stream that run beside the side branch's full-chip weight-gradient launch in the
+// pipelined step (orn_engine.hip): where a SIMD hosts a wave of each, this one issues first -- the caller's stream is the critical
+// path, the side branch has slack (same box, 720p step: 1.045 -> 1.036 ms).  Alone on the chip (serial steps) it changes nothing.
+#define ORN_PRIO_HIGH() __builtin_amdgcn_s_setprio(2)
 static inline int orn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t orn_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 

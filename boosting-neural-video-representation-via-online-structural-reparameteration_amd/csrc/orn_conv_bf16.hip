@@ -252,6 +252,7 @@ __device__ __forceinline__ void conv_mfma_step(h16x8 (&fa)[NSET][2 * MB], h16x8 
 template <int WAVES_M, int WAVES_N, int MB, int NB, int EPI, int CK = CB_CK, bool ALLTAPS = (CK != CB_CK)>
 __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_nhwc_bf16(ConvBP p)
 {
+    ORN_PRIO_HIGH();
     static_assert(!EPI_IS_FWD(EPI) && CK == CB_CK, "this file holds the dgrad kernels (forward: orn_conv_fwd_bf16.hip)");
     constexpr bool NARROW = false;
     constexpr int NCH = CK / 8;                        // 16-byte chunks per LDS row
@@ -670,9 +671,10 @@ __device__ __forceinline__ void head_finish_body(const float *__restrict__ parti
 }
 
 // The head's dW/db reduction (needed by Adam only) rides along as trailing work-groups: one graph node less.
-struct WgradBPAll { int n; int start[ORN_MAX_LAYERS + 1]; WgradBP p[ORN_MAX_LAYERS]; OrnHeadFinish hf; int hf_blocks; OrnStemL2Job l2; };
+struct WgradBPAll { int n; int start[ORN_MAX_LAYERS + 1]; WgradBP p[ORN_MAX_LAYERS]; OrnHeadFinish hf; int hf_blocks; OrnStemL2Job l2; int side; };
 __global__ void __launch_bounds__(256, 2) k_wgrad_nhwc_bf16_all(WgradBPAll a)
 {
+    if (!a.side) ORN_PRIO_HIGH();         // (the side branch's launch keeps the default priority: orn_common.h)
     if ((int)blockIdx.x >= a.start[a.n] + a.hf_blocks) {        // stem backward, second linear layer: 16 output rows per work-group
         extern __shared__ __attribute__((aligned(16))) unsigned char smem_l2[];
         orn_stem_l2_block(a.l2, (int)blockIdx.x - a.start[a.n] - a.hf_blocks, (int)threadIdx.x, reinterpret_cast<float *>(smem_l2));
@@ -806,12 +808,13 @@ static int wgrad_fill(WgradBP &p, const h16 *xpad, const h16 *dypad, int H, int 
 }
 
 // slabs only (no reduction), several layers in one launch
-int orn_launch_wgrad_bf16_batch(int n, const OrnWgradJob *J, hipStream_t st, const OrnHeadFinish *hf, const OrnStemL2Job *l2)
+int orn_launch_wgrad_bf16_batch(int n, const OrnWgradJob *J, hipStream_t st, const OrnHeadFinish *hf, const OrnStemL2Job *l2, int side)
 {
     if (n == 0 && !hf && !l2) return 0;
     ORN_REQUIRE(n <= ORN_MAX_LAYERS, "wgrad_batch: %d layers", n);
     WgradBPAll a;
     a.n = n;
+    a.side = side;
     int total = 0;
     for (int i = 0; i < n; ++i) {
         ORN_TRY(wgrad_fill(a.p[i], (const h16 *)J[i].xpad, (const h16 *)J[i].dypad, J[i].H, J[i].W, J[i].C, J[i].O, J[i].s, J[i].slabs, J[i].smax));

@@ -185,6 +185,7 @@ __device__ __forceinline__ void convf_wait_set(h16x8 (&fa)[NSET][MB], h16x8 (&fb
 template <int WAVES_M, int WAVES_N, int MB, int NB, int EPI, int CK = CB_CK, bool ALLTAPS = (CK != CB_CK)>
 __global__ void __launch_bounds__(WAVES_M *WAVES_N * 64) k_conv_fwd_nhwc_bf16(ConvFP p)
 {
+    ORN_PRIO_HIGH();
     static_assert(EPI_IS_FWD(EPI), "this file holds the forward kernel only (dgrad: orn_conv_bf16.hip)");
     constexpr bool NARROW = (CK != CB_CK);
     static_assert(CK == CB_CK || (CK == 32 && EPI_IS_FWD(EPI)), "narrow form: 32 channels, forward only");

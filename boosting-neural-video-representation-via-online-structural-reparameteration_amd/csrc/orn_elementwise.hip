@@ -648,6 +648,7 @@ __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float
                        float omb1, float beta2, float omb2, float eps, float inv_gscale, const float *__restrict__ gmask,
                        OrnScaleState *sc, OrnScaleState *sc_master, OrnScaleState *mirror)
 {
+    ORN_PRIO_HIGH();
     // non-finite gradients somewhere in this step: leave parameters and moments alone (the whole step is skipped)
     if (sc && sc->flag) {
         if (blockIdx.x == 0 && threadIdx.x == 0) {

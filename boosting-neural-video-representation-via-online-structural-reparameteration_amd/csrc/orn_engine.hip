@@ -625,6 +625,19 @@ static int last_smax(const orn_engine *e)
     return e->pipe_ok ? smax : 0;
 }
 
+// Where the side branch forks off the backward: behind the dgrad launch of this layer (n_layers: behind the head's backward);
+// -1: behind the lower blocks' weight gradients and their reduction, in front of the merge backward.  Default: behind the dgrad of
+// the block below the last one.  Measured on the 720p step, one box (tools/probes/mode_ab.sh; serial 1.079 ms): fork behind layer
+// 5 (the head) 1.038, 4 1.058, 3 1.024, 2 1.032, 1 1.035, 0 1.067, -1 1.050 ms -- the last block's own dgrad and the launch behind
+// it are full-chip MFMA launches that the side branch's weight gradient only thrashes; behind them the caller's stream runs
+// under-filled launches, and the earlier the branch starts the earlier it is back for the next forward.
+static int side_fork_at(const orn_engine *e)
+{
+    static const int at = orn_probe_env_int("ORN_SIDE_FORK", -2);
+    if (at == -2) return e->d.n_layers - 2 > e->ff ? e->d.n_layers - 2 : -1;      // default
+    return at > e->d.n_layers ? e->d.n_layers : at;
+}
+
 // The side branch of a pipelined step, first half (enqueued where the caller's stream has finished the dgrad chain and the lower
 // blocks' weight gradients): the last block's weight gradient (+ the head's dW / db finish), its slab reduction, its merge backward.
 static int side_branch_backward(orn_engine *e, hipStream_t st)
@@ -639,7 +652,7 @@ static int side_branch_backward(orn_engine *e, hipStream_t st)
     ORN_HIP(hipStreamWaitEvent(sd, e->ev_fork, 0));
     const OrnWgradJob wj = {e->L[nl - 1].xpad, e->L[nl - 1].dypad, l.H, l.W, l.C, l.O, l.s, e->L[nl - 1].wslab, last_smax(e)};
     const OrnHeadFinish hf = {e->head_ws, e->ops->head_bwd_blocks(e->Hout, e->Wout), e->Cn_last, 1.0f / e->gs, G + d.head_w, G + d.head_b, sc};
-    ORN_TRY(e->ops->wgrad_batch(1, &wj, sd, &hf, nullptr));
+    ORN_TRY(e->ops->wgrad_batch(1, &wj, sd, &hf, nullptr, 1));
     ORN_HIP(hipEventRecord(e->ev_wgrad, sd));           // the last block's input buffer is free again
     const OrnWgradReduce wr = {e->L[nl - 1].wslab, l.H, l.W, l.C, l.O, l.s, 1.0f / e->gs, G + l.w3x3, G + l.b3x3, sc, last_smax(e)};
     ORN_TRY(e->ops->wgrad_reduce_all(1, &wr, sd, nullptr));
@@ -654,7 +667,9 @@ static int side_branch_backward(orn_engine *e, hipStream_t st)
 
 // Second half (enqueued behind the caller's Adam launch, whose skip decision it follows): Adam over the last block's and the head's
 // parameters, then the last block's merge forward (or, without ERB, its 16-bit operand copies) for the NEXT step.
-static int side_branch_update(orn_engine *e)
+// more: another step follows in this call (the last step of a call skips the merge forward: the next call's first step merges every
+// block itself, the parameters may have been touched in between)
+static int side_branch_update(orn_engine *e, bool more)
 {
     const orn_engine_desc &d = e->d;
     const int nl = d.n_layers;
@@ -663,7 +678,8 @@ static int side_branch_update(orn_engine *e)
     ORN_HIP(hipStreamWaitEvent(sd, e->ev_adam, 0));
     ORN_TRY(orn_launch_adam(e->params + lo, e->grads + lo, e->m + lo, e->v + lo, (size_t)d.n_params - lo, 0.0, 1, e->cur_side, d.beta1, d.beta2,
                             d.eps, 1.0f, sd, e->gmask ? e->gmask + lo : nullptr, e->sc_side, nullptr, nullptr, false));
-    if (d.erb) {
+    if (!more) {
+    } else if (d.erb) {
         const orn_engine::MergeSet &ms = e->mset[2];
         int pk_par = 0, pk_t = 0;
         const void *pk = ms.mh_host ? orn_merge_h16_pack(ms.mh_host, &pk_par, &pk_t) : nullptr;
@@ -684,7 +700,7 @@ static int side_branch_update(orn_engine *e)
 // pipe: the pipelined form (struct orn_engine, `side`): the last block's weight-gradient chain leaves this step on the side stream
 static int train_step(orn_engine *e, const float *frames, const float *embeds, const orn_step_sched *sched,
                       int32_t *cursor, float *stats_out, int32_t n_slots, hipStream_t st, int adv_count = 1, int cur_idx = 0,
-                      bool pipe = false)
+                      bool pipe = false, bool more = false)
 {
     const orn_engine_desc &d = e->d;
     float *P = e->params, *G = e->grads;
@@ -718,6 +734,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         for (int i = 0; i < nl; ++i) { wfs[i] = e->L[i].wf; wds[i] = e->L[i].wd32; Os[i] = d.layer[i].O; Cs[i] = d.layer[i].C; }
         ORN_TRY(orn_launch_flip_transpose_all(nl, wfs, wds, Os, Cs, st));
     }
+    if (pipe && side_fork_at(e) >= nl) ORN_TRY(side_branch_backward(e, st));
     for (int i = nl - 1; i >= 0; --i) {
         const orn_layer_desc &l = d.layer[i];
         LayerBuf &b = e->L[i];
@@ -746,6 +763,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         ORN_TRY(orn_launch_conv_bwd_f32(x, b.wf, b.z, b.da, 1, l.C, l.O, l.H, l.W, l.s, dx, G + l.w3x3, G + l.b3x3, e->scratch, st,
                                         (i == nl - 1 && head_fused32) ? &hfuse : nullptr, ff >= nl ? b.wd32 : nullptr));
         if (e->prof) (void)hipEventRecord(e->prof_ev[2 * ORN_MAX_LAYERS + 2 * i + 1], st);
+        if (pipe && i == side_fork_at(e)) ORN_TRY(side_branch_backward(e, st));
     }
     // stem backward; with a wgrad batch behind it, its last kernel (needed by Adam only) rides along that launch
     OrnStemW0Job w0job;
@@ -768,7 +786,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         }
         const OrnHeadFinish hf = {e->head_ws, e->ops->head_bwd_blocks(e->Hout, e->Wout), e->Cn_last, 1.0f / e->gs, G + d.head_w, G + d.head_b, sc};
         if (e->prof) (void)hipEventRecord(e->prof_ev[4 * ORN_MAX_LAYERS], st);
-        ORN_TRY(e->ops->wgrad_batch(nj, wj, st, pipe ? nullptr : &hf, &l2job));
+        ORN_TRY(e->ops->wgrad_batch(nj, wj, st, pipe ? nullptr : &hf, &l2job, 0));
         if (e->prof) (void)hipEventRecord(e->prof_ev[4 * ORN_MAX_LAYERS + 1], st);
         OrnWgradReduce wr[ORN_MAX_LAYERS];
         for (int i = ff; i < n_main; ++i) {
@@ -779,7 +797,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         ORN_TRY(e->ops->wgrad_reduce_all(n_main - ff, wr, st, &w0job));
         if (e->prof) (void)hipEventRecord(e->prof_ev[4 * ORN_MAX_LAYERS + 3], st);
     }
-    if (pipe) ORN_TRY(side_branch_backward(e, st));     // fork: the last block's wgrad .. merge backward, on the side stream
+    if (pipe && side_fork_at(e) < 0) ORN_TRY(side_branch_backward(e, st));     // fork: the last block's wgrad .. merge backward, on the side stream
     if (d.erb) {
         // merge backward of every layer (closed forms): dW3 & dT, then dW2 & dW1, then the slices
         const orn_engine::MergeSet &ms = e->mset[pipe ? 1 : 0];
@@ -797,7 +815,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         // this stream's Adam launch covers everything below the last block; its skip decision is mirrored for the side branch's launch
         ORN_TRY(orn_launch_adam(P, G, e->m, e->v, e->side_lo, 0.0, 1, cur, d.beta1, d.beta2, d.eps, 1.0f, st, e->gmask, sc, e->sc, e->sc_side));
         ORN_HIP(hipEventRecord(e->ev_adam, st));
-        return side_branch_update(e);
+        return side_branch_update(e, more);
     }
     ORN_TRY(orn_launch_adam(P, G, e->m, e->v, (size_t)d.n_params, 0.0, 1, cur, d.beta1, d.beta2, d.eps, 1.0f, st, e->gmask, sc, e->sc));
     return 0;
@@ -822,7 +840,7 @@ extern "C" int orn_engine_train_steps(orn_engine *e, const float *frames, const 
     ORN_REQUIRE(e->grads && e->m && e->v, "engine_train_steps: engine was created without grads / Adam arenas");
     hipStream_t st = (hipStream_t)stream;
     int rc = 0;
-    for (int k = 0; k < n_steps && rc == 0; ++k) rc = train_step(e, frames, embeds, sched, cursor, stats_out, n_slots, st, 1, 0, e->pipe_ok);
+    for (int k = 0; k < n_steps && rc == 0; ++k) rc = train_step(e, frames, embeds, sched, cursor, stats_out, n_slots, st, 1, 0, e->pipe_ok, k + 1 < n_steps);
     if (e->side_busy) {
         const hipError_t hrc = hipStreamWaitEvent(st, e->ev_join, 0);
         e->side_busy = false;

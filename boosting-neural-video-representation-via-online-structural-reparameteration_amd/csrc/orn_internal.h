@@ -129,7 +129,7 @@ struct OrnHalfOps {
     size_t (*wgrad_ws_floats)(int H, int W, int O);
     int (*wgrad)(const void *xpad, const void *dypad, int H, int W, int C, int O, int s, float gscale, float *slabs, float *dwf,
                  float *dbf, hipStream_t st);
-    int (*wgrad_batch)(int n, const OrnWgradJob *J, hipStream_t st, const OrnHeadFinish *hf, const OrnStemL2Job *l2);   // several layers' slabs in one launch (+ optional head finish, + the stem backward's first kernel)
+    int (*wgrad_batch)(int n, const OrnWgradJob *J, hipStream_t st, const OrnHeadFinish *hf, const OrnStemL2Job *l2, int side);   // side: launched on the engine's side stream (default wave priority)   // several layers' slabs in one launch (+ optional head finish, + the stem backward's first kernel)
     int (*wgrad_reduce_all)(int n, const OrnWgradReduce *L, hipStream_t st, const OrnStemW0Job *w0);   // all layers' reductions in one launch (+ the stem backward's last kernel)
     int (*prep_all)(int n, const OrnPrepLayer *L, hipStream_t st);
     int (*to_nhwc)(const float *src, int C, int Cp, int H, int W, void *dst, hipStream_t st);

@@ -547,6 +547,7 @@ __global__ void __launch_bounds__(256) k_gemm_f32_grouped(const GemmGroup *__res
 __global__ void __launch_bounds__(256) k_gemm_f32_grouped_linear(const GemmGroup *__restrict__ g, OrnLinearJob job, int gemm_tiles, int lin_blocks,
                                                                  MhPackAll pack, int tile_off)
 {
+    ORN_PRIO_HIGH();
     // one dynamic array for every role of the launch, sized for the launch's tile shape: the static 60 KB of the larger
     // shape held the S launch to two work-groups per CU, and its ~2,400 short rider work-groups queued behind the 320 GEMM
     // tiles for the remaining slots -- 19 us beyond the tiles' own 23
@@ -783,6 +784,7 @@ struct W2TAll { int n; int blk_start[ORN_MAX_LAYERS + 1]; struct { const float *
 
 __global__ void __launch_bounds__(256) k_w2_transpose(W2TAll a, MhPackAll pack, int tr_blocks)
 {
+    ORN_PRIO_HIGH();
     extern __shared__ float w2s[];
     if ((int)blockIdx.x >= tr_blocks) {                    // riders: parameter-side half copies for the merge backward
         int layer, pjob;
@@ -1007,6 +1009,7 @@ __global__ void k_merge_bias_all(MiscLayers m)
 // slices of dWf into the 1x3 / 3x1 branches, bias fan-out, and dW1 = fixed-order sum of its 9 partials
 __global__ void k_merge_bwd_tail_all(MiscLayers m)
 {
+    ORN_PRIO_HIGH();
     const OrnMergeMisc &l = m.l[blockIdx.y];
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long OC = (long)l.O * l.C;

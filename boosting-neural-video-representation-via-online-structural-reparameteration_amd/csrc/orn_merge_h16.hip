@@ -50,6 +50,7 @@ size_t orn_merge_h16_layer_halfs(int C, int O)
 // ---- pack (orn_merge_pack.h): the gradient-side jobs; the parameter-side ones ride along the forward merge ---------
 __global__ void __launch_bounds__(256) k_merge_pack(MhPackAll a, int fwd /* table: MH_TAB_* */)
 {
+    ORN_PRIO_HIGH();
     __shared__ float tile[64][65];
     int layer, job;
     const int blk = mh_pack_decode(a, fwd, (int)blockIdx.x, layer, job);
@@ -77,6 +78,7 @@ struct MhGroup { int n; int tile_start[MH_MAXP + 1]; MhProb p[MH_MAXP]; };
 // HBM for operands written a launch ago), ~27 us for 3 GFLOP.
 __global__ void __launch_bounds__(256) k_mgemm_h16(const MhGroup *__restrict__ g, int total_tiles)
 {
+    ORN_PRIO_HIGH();
     __shared__ float part[4][16][64];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, l31 = lane & 31, hh = lane >> 5;

@@ -97,6 +97,7 @@ __device__ __forceinline__ void batch_store(const float (&v)[U], const bool (&ok
 template <typename H16>
 __global__ void __launch_bounds__(1024) k_stage0_fwd(Stage0P p, MhPackAll pack)
 {
+    ORN_PRIO_HIGH();
     extern __shared__ float sm[];
     if ((int)blockIdx.x >= p.fwd_blocks) {            // riders: nothing in this launch depends on them
         const int rb = (int)blockIdx.x - p.fwd_blocks;
@@ -178,6 +179,7 @@ __global__ void __launch_bounds__(1024) k_stage0_fwd(Stage0P p, MhPackAll pack)
 // requests from 41 CUs: ~17 us).
 __global__ void __launch_bounds__(1024) k_stage0_bwd(Stage0P p)
 {
+    ORN_PRIO_HIGH();
     extern __shared__ float sm[];
     const int C = p.C, C16 = p.C16, H = p.H, W = p.W, HW = H * W, XW = W + 2, XP = (H + 2) * XW, WN = 9 * C16 + 4;
     float *xs = sm, *ws_ = sm + C16 * XP, *dys = ws_ + 16 * WN;       // dys: [16][H+2][W+2], zero border

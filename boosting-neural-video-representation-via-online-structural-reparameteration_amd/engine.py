@@ -125,6 +125,7 @@ class TrainEngine:
         self.frames = None
         self.embeds = None
         self.global_step = 0
+        self.skipped_carry = 0                             # steps skipped by engines this one replaced (main_train fall-back)
         Hs, Ws = model.fc_h, model.fc_w
         for blk in model.layers:
             Hs, Ws = Hs * blk.stride, Ws * blk.stride
@@ -238,6 +239,12 @@ class TrainEngine:
         self.global_step += 1
         v = [float(x) for x in ms]
         return {'fwd': v[:n], 'dgrad': v[n:2 * n], 'wgrad': v[2 * n], 'wgrad_reduce': v[2 * n + 1]}
+
+    def applied_steps(self) -> int:
+        """Optimiser steps that changed the parameters so far: enqueued steps minus the ones the non-finite guard skipped, in this
+        engine (device counter) and in engines it replaced (`skipped_carry`, set by main_train's precision fall-back).  This is
+        torch.optim.Adam's 'step' of a checkpoint (include/orn.h).  Synchronises."""
+        return int(self.global_step - self.skipped_carry - self.scale_state()['skipped'])
 
     def scale_state(self) -> dict:
         """Dynamic loss scale / non-finite guard of the engine (device state; synchronises): scale, ceiling, flag, steps

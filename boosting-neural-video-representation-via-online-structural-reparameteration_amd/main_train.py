@@ -144,7 +144,7 @@ class Best:
         self.val_msssim = torch.tensor(0.0)
 
 
-def save_checkpoint(args, model, eng, epoch, best, name='model_latest.pth', deploy_too=None):
+def save_checkpoint(args, model, eng, epoch, best, name='model_latest.pth', deploy_too=None, applied=None):
     """main_train.py:293-301,327 layout; ERB also writes the deploy copy (main_train.py:325-351).  `best`: a Best, or a
     number (train PSNR; kept for callers that only track that)."""
     from . import checkpoint
@@ -152,7 +152,7 @@ def save_checkpoint(args, model, eng, epoch, best, name='model_latest.pth', depl
         b = Best()
         b.train_psnr = b.val_psnr = torch.as_tensor(float(best))
         best = b
-    opt = adam_state_dict(model, eng, args)
+    opt = adam_state_dict(model, eng, args, applied)
     kw = dict(train_best_psnr=best.train_psnr, val_best_psnr=best.val_psnr, train_best_msssim=best.train_msssim,
               val_best_msssim=best.val_msssim)
     checkpoint.save(os.path.join(args.outf, name), model, epoch + 1, opt, **kw)
@@ -168,6 +168,7 @@ class Snapshot:
     def __init__(self, eng, epoch):
         self.params, self.m, self.v = eng.params.clone(), eng.adam_m.clone(), eng.adam_v.clone()
         self.step, self.epoch = eng.global_step, epoch
+        self.applied = eng.applied_steps()          # optimiser steps actually applied up to this moment (skipped ones excluded)
 
     def restore(self, eng):
         eng.params.copy_(self.params); eng.adam_m.copy_(self.m); eng.adam_v.copy_(self.v)
@@ -178,7 +179,7 @@ class Snapshot:
         now = Snapshot(eng, -1)
         self.restore(eng)
         try:
-            save_checkpoint(args, model, eng, self.epoch, best, name)
+            save_checkpoint(args, model, eng, self.epoch, best, name, applied=self.applied)     # Adam's count as it stood at the snapshot
         finally:
             now.restore(eng)
 
@@ -197,12 +198,13 @@ def skipped_steps_warning(skipped_before: int, skipped_now: int, steps: int, pre
             f'Re-run with --precision fp32' + (' or bf16' if precision == 'fp16' else '') + ' or a lower --lr.')
 
 
-def adam_state_dict(model, eng, args):
+def adam_state_dict(model, eng, args, applied=None):
     """The optimizer entry of a checkpoint in torch.optim.Adam's own state_dict layout (per-parameter 'step' / 'exp_avg' /
     'exp_avg_sq' in model.parameters() order + one param group), so the reference's
     `optimizer.load_state_dict(checkpoint['optimizer'])` (main_eval.py:409, main_train.py:207-212) reads it."""
     state = {}
-    step = float(eng.global_step - eng.scale_state()['skipped'])      # a skipped step does not advance torch's Adam either
+    # a skipped step does not advance torch's Adam either; `applied`: the count of an earlier moment (a Snapshot being written)
+    step = float(eng.applied_steps() if applied is None else applied)
     for i, (k, p) in enumerate(model.named_parameters()):
         off, n = eng.layout[k]
         state[i] = {'step': torch.tensor(step), 'exp_avg': eng.adam_m[off:off + n].view(p.shape).cpu().clone(),
@@ -307,7 +309,10 @@ def fit_video(args, name, vid_index, rank, _inject=None):
             _inject(epoch, eng)
         g.manual_seed(args.manualSeed + epoch)
         order = torch.randperm(n, generator=g).tolist()[:steps_per_epoch]
-        entries = [(f, epoch * steps_per_epoch + i + 1, utils.lr_value(epoch % args.epochs, i, n, args)) for i, f in enumerate(order)]
+        # Adam's step numbers: the device subtracts the steps THIS engine skipped; steps skipped by an engine a fall-back replaced
+        # (eng.skipped_carry) are taken off here, so the bias corrections count applied steps only, whatever the history
+        entries = [(f, epoch * steps_per_epoch + i + 1 - eng.skipped_carry, utils.lr_value(epoch % args.epochs, i, n, args))
+                   for i, f in enumerate(order)]
         eng.set_schedule(entries)
         eng.run(len(entries))
         st = eng.stats(len(entries))                                 # syncs once per epoch
@@ -321,11 +326,13 @@ def fit_video(args, name, vid_index, rank, _inject=None):
             say(warn.split(' Re-run')[0] + f' Restoring the start of epoch {epoch + 1} and continuing in --precision {wider}.')
             epoch_start.restore(eng)
             step0 = eng.global_step
+            carry = step0 - epoch_start.applied                          # steps skipped before the restored epoch began, by any engine
             m0, v0 = eng.adam_m.clone(), eng.adam_v.clone()
             del eng
             eng = oeng.TrainEngine(model, loss_type=args.loss_type, beta=args.beta, precision=wider)
             eng.adam_m.copy_(m0); eng.adam_v.copy_(v0)
             eng.global_step = step0
+            eng.skipped_carry = carry                                   # the new engine's own counter starts at 0
             eng.set_video(frames, embeds)
             precision, skipped_before = wider, 0
             best_snap = None if best_snap is None else best_snap       # (arena-sized tensors: still valid for the new engine)

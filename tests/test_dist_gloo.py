@@ -20,10 +20,16 @@ vids = du.shard_videos(7, world, rank)
 assert vids == ([0, 2, 4, 6] if rank == 0 else [1, 3, 5])
 dt = du.max_over_ranks(dist, 1.0 + rank)          # rank 1 is slower
 assert dt == 2.0, dt
-recs = du.gather_records(dist, [30.0 + rank, 0.9, 100.0 * (rank + 1), 1.0 + rank, 100 * (rank + 1)])
-assert len(recs) == 2 and recs[0][0] == 30.0 and recs[1][0] == 31.0
+# record layout: [psnr SUM over the rank's videos, videos fitted, frames, seconds, steps]; rank 0 fitted 4 videos, rank 1 three
+nv = len(vids)
+recs = du.gather_records(dist, [30.0 * nv + rank, float(nv), 100.0 * (rank + 1), 1.0 + rank, 100 * (rank + 1)])
+assert len(recs) == 2 and recs[0][0] == 120.0 and recs[1][0] == 91.0 and recs[0][1] == 4.0 and recs[1][1] == 3.0
 agg = du.aggregate(recs, dt)
 assert abs(agg["frames_per_s"] - 150.0) < 1e-6 and agg["ranks"] == 2
+assert agg["videos"] == 7 and abs(agg["mean_psnr"] - 211.0 / 7) < 1e-5, agg      # mean over the VIDEOS of the job
+# a rank without a video (8 ranks, 7 videos) contributes nothing to the mean
+idle = du.aggregate([[60.0, 2.0, 10.0, 1.0, 10.0], [0.0, 0.0, 0.0, 0.0, 0.0]], 1.0)
+assert idle["videos"] == 2 and abs(idle["mean_psnr"] - 30.0) < 1e-6 and idle["ranks"] == 2, idle
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")

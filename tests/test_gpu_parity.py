@@ -403,37 +403,41 @@ def test_engine_matches_oracle_training(orn, bt, graph):
     assert torch.allclose(img_e, img_m, rtol=0, atol=1e-6)
 
 
-_ORACLE_720P = {}
+_ORACLE_STEP = {}
+_GEO = {'720p': ('9_16_26', [5, 2, 2, 2, 2], (720, 1280)),          # BASELINE configs 1 / 2
+        '1080p': ('9_16_48', [5, 3, 2, 2, 2], (1080, 1920))}        # BASELINE config 3
 
 
-def _oracle_720p_step():
-    """One Fusion6 training step of BASELINE config 2 at full size on the CPU oracle (autograd), computed once per session."""
-    if not _ORACLE_720P:
+def _make_full(orn, geo, bt):
+    torch.manual_seed(1)
+    fc, strides, _ = _GEO[geo]
+    return orn.model.Generator(embed_length=80, stem_dim_num='512_1', fc_hw_dim=fc, expansion=1, num_blocks=1, norm='none', act='swish',
+                               bias=True, reduction=2, conv_type='conv', stride_list=strides, sin_res=True, lower_width=96,
+                               sigmoid=False, deploy=False, branch_type=bt)
+
+
+def _oracle_full_step(geo='720p', bt='ERB'):
+    """One Fusion6 training step at FULL size on the CPU oracle (autograd), computed once per session and (geometry, branch type)."""
+    key = (geo, bt)
+    if key not in _ORACLE_STEP:
         from oracle import cpu_ref
-        torch.manual_seed(1)
         import orn_amd
-        gen = _make_720p(orn_amd)
+        fc, strides, (h, w) = _GEO[geo]
+        gen = _make_full(orn_amd, geo, bt)
         sd = {k: v.detach().clone() for k, v in gen.state_dict().items()}
-        frames = cpu_ref.synthetic_video(2, 720, 1280, seed=11)
+        frames = cpu_ref.synthetic_video(2, h, w, seed=11)
         embeds = cpu_ref.positional_encoding(torch.tensor([0.0, 0.5]), 1.25, 40)
         am = {k: torch.zeros_like(v) for k, v in sd.items()}
         av = {k: torch.zeros_like(v) for k, v in sd.items()}
-        loss, psnr, ref = cpu_ref.train_step({k: v.clone() for k, v in sd.items()}, am, av, 1, 0.0, embeds[1:2], frames[1:2], '9_16_26',
-                                             [5, 2, 2, 2, 2], 'ERB', 'Fusion6', 0.5)
-        _ORACLE_720P.update(sd=sd, frames=frames, embeds=embeds, loss=loss.item(), psnr=psnr.item(), ref=ref)
-    return _ORACLE_720P
+        loss, psnr, ref = cpu_ref.train_step({k: v.clone() for k, v in sd.items()}, am, av, 1, 0.0, embeds[1:2], frames[1:2], fc,
+                                             strides, bt, 'Fusion6', 0.5)
+        _ORACLE_STEP[key] = dict(sd=sd, frames=frames, embeds=embeds, loss=loss.item(), psnr=psnr.item(), ref=ref)
+    return _ORACLE_STEP[key]
 
 
-@pytest.mark.parametrize('prec', ['fp32', 'fp16', 'bf16'])
-def test_720p_gradients_vs_oracle(orn, prec):
-    """BASELINE config 2 at FULL size: loss, PSNR and every one of the 51 gradient tensors of one Fusion6 training
-    step of the engine -- in its fp32 mode AND in the 16-bit modes bench.py's headline runs in -- against the CPU ORACLE's
-    autograd on the same seeded model and frame (lr 0, so the parameters stay put).  Tolerances, relative L2 per tensor:
-    fp32 2e-3 (accumulation order: MFMA split-K vs ATen); fp16 1e-2 (11-bit activations / weights, fp32 accumulate);
-    bf16 5e-2 (8-bit).  Loss within 5e-5 / 3e-4 / 2e-3 relative, PSNR of the prediction within 1e-3 / 0.01 / 0.05 dB."""
-    o = _oracle_720p_step()
-    torch.manual_seed(1)
-    gen = _make_720p(orn)
+def _check_full_step(orn, geo, bt, prec, n_grads):
+    o = _oracle_full_step(geo, bt)
+    gen = _make_full(orn, geo, bt)
     gen.load_state_dict(o['sd'])
     eng = orn.engine.TrainEngine(gen, loss_type='Fusion6', beta=0.5, precision=prec)
     eng.set_video(o['frames'], o['embeds'])
@@ -446,10 +450,34 @@ def test_720p_gradients_vs_oracle(orn, prec):
     tol_loss, tol_psnr, tol_g = {'fp32': (5e-5, 1e-3, 2e-3), 'fp16': (3e-4, 0.01, 1e-2), 'bf16': (2e-3, 0.05, 5e-2)}[prec]
     assert abs(st[0] - o['loss']) <= tol_loss * abs(o['loss']), (st[0], o['loss'])
     assert abs(st[4] - o['psnr']) < tol_psnr, (st[4], o['psnr'])
-    assert len(ref) == 51
+    assert len(ref) == n_grads
     rel = sorted(((float((grads[k] - ref[k].flatten()).norm() / (ref[k].norm() + 1e-30)), k) for k in ref), reverse=True)
     assert rel[0][0] < tol_g, rel[:8]
     assert eng.scale_state()['skipped'] == 0
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'fp16', 'bf16'])
+def test_720p_gradients_vs_oracle(orn, prec):
+    """BASELINE config 2 at FULL size: loss, PSNR and every one of the 51 gradient tensors of one Fusion6 training
+    step of the engine -- in its fp32 mode AND in the 16-bit modes bench.py's headline runs in -- against the CPU ORACLE's
+    autograd on the same seeded model and frame (lr 0, so the parameters stay put).  Tolerances, relative L2 per tensor:
+    fp32 2e-3 (accumulation order: MFMA split-K vs ATen); fp16 1e-2 (11-bit activations / weights, fp32 accumulate);
+    bf16 5e-2 (8-bit).  Loss within 5e-5 / 3e-4 / 2e-3 relative, PSNR of the prediction within 1e-3 / 0.01 / 0.05 dB."""
+    _check_full_step(orn, '720p', 'ERB', prec, 51)
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'fp16'])
+def test_720p_vanilla_gradients_vs_oracle(orn, prec):
+    """BASELINE config 1's geometry (branch_type=NeRV_vanilla, 9_16_26, 720p; model.py:320-322,521-523) at FULL size against the
+    CPU oracle: 16 gradient tensors.  Vanilla's 16-bit operand copies come from the prep launch, not from the merge epilogue as
+    ERB's do, and its large launches (>= 128 / >= 400 pixel tiles, the slabbed wgrad) are otherwise only run by ERB models."""
+    _check_full_step(orn, '720p', 'NeRV_vanilla', prec, 16)
+
+
+def test_1080p_fp32_gradients_vs_oracle(orn):
+    """BASELINE config 3's geometry (ERB, 9_16_48, strides 5 3 2 2 2, 1920x1080) at FULL size: the fp32 engine's loss, PSNR and 51
+    gradient tensors against the CPU oracle (the 16-bit engines are compared with the fp32 engine at this size in test_gpu_bf16)."""
+    _check_full_step(orn, '1080p', 'ERB', 'fp32', 51)
 
 
 def test_engine_merge_is_bit_exact(orn):

@@ -12,10 +12,10 @@ tabs = [r[0] for r in c.execute("select name from sqlite_master where type in ('
 cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
 qcol = 'queue_id' if 'queue_id' in cols else ('stream_id' if 'stream_id' in cols else None)
 rows = list(c.execute(f"select name,start,end,grid_x*grid_y*grid_z/(workgroup_x*workgroup_y*workgroup_z),workgroup_x{',' + qcol if qcol else ''} from kernels order by start"))
-idx = [i for i, r in enumerate(rows) if 'k_adam' in r[0]]
+idx = [i for i, r in enumerate(rows) if 'k_advance' in r[0]]          # one per step (eager / stream modes; one per graph launch in graph mode)
 back = min(back, len(idx) - 2)
-a, b = idx[-1 - back - 1], idx[-1 - back]
-t0 = rows[a][2]
+a, b = idx[-1 - back - 1] - 1, idx[-1 - back] - 1
+t0 = rows[a + 1][1]
 busy_end = t0
 tot = 0
 for r in rows[a + 1:b + 1]:
@@ -27,4 +27,4 @@ for r in rows[a + 1:b + 1]:
     tot += d
     q = f' q={r[5]}' if qcol else ''
     print(f"{nm:56s} wg={r[3]:6d}x{r[4]:4d} {(r[1] - t0) / 1e3:8.1f} -> {(r[2] - t0) / 1e3:8.1f}  {d:7.1f} us{q}{ov}")
-print('sum of kernels', round(tot, 1), 'span', (rows[b][2] - rows[a][2]) / 1e3)
+print('sum of kernels', round(tot, 1), 'span (advance to advance)', (rows[b + 1][1] - rows[a + 1][1]) / 1e3)
