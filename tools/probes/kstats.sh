@@ -1,9 +1,11 @@
-# per-kernel time of one training step under rocprofv3 for a given library build.  usage: kstats.sh <lib.so> <tag>  -> gpurun_out/kstats_<tag>.txt
-lib=$1; tag=$2
+# per-kernel time of one training step under rocprofv3 for a given library build.  usage: kstats.sh <lib.so> <tag> [bench flags]  -> gpurun_out/kstats_<tag>.txt
+# default flags: --mode graph (the SERIAL step: one kernel at a time, so the per-symbol times add up to the step; in --mode stream the side
+# branch's launches overlap the caller's stream and the sum exceeds the step: use timeline.sh for that picture)
+lib=$1; tag=$2; shift 2; flags="$@"; [ -z "$flags" ] && flags="--mode graph"
 export ORN_LIB_PATH=$(realpath $lib)
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ks_$tag
-rocprofv3 --kernel-trace --stats -d /tmp/ks_$tag -o k --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fp32 --quick --steps 40 --warmup 12 > /tmp/ks_$tag.log 2>&1
-python3 - $tag <<'PY' > $GRAFT_REPO_ROOT/gpurun_out/kstats_$2.txt
+rocprofv3 --kernel-trace --stats -d /tmp/ks_$tag -o k --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fp32 --quick --steps 40 --warmup 12 $flags > /tmp/ks_$tag.log 2>&1
+python3 - $tag <<'PY' > $GRAFT_REPO_ROOT/gpurun_out/kstats_$tag.txt
 import csv, glob, sys, collections
 tag = sys.argv[1]
 f = glob.glob(f'/tmp/ks_{tag}/**/*kernel_trace.csv', recursive=True)[0]

@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_s_$c
-  rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_s_$c -o t --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fp32 --quick --steps 4 --warmup 2 > /tmp/pmc_s_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_s_$c -o t --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fp32 --quick --mode graph --steps 4 --warmup 2 > /tmp/pmc_s_$c.log 2>&1
   tail -1 /tmp/pmc_s_$c.log | cut -c1-200
 done
 python3 - > $GRAFT_REPO_ROOT/gpurun_out/conv_traffic.json <<'PY'
@@ -43,7 +43,7 @@ for i in range(ff, nl):
 out = {'csrc_hash': bench.csrc_hash(),      # the build these numbers belong to: bench.py refuses the file for any other
        'unit': 'bytes per launch (mean over the launches of the symbol in the step)',
        'shape': 'BASELINE config 2 training step (720p, ERB), fp16 engine: the launches bench.py times',
-       'method': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over bench.py --steps 4 --warmup 2 '
+       'method': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over bench.py --mode graph --steps 4 --warmup 2 '
                  '(graph replays + the eager profile steps); counters are KiB; reads corrected x2 per MI355X_MICROARCH.md (HBM section)',
        'kernels': []}
 for k, cs in sorted(acc.items()):
