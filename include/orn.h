@@ -265,7 +265,15 @@ ORN_API int orn_engine_train_steps_graph(orn_engine *e, const float *frames, con
  *  - the merge backward of the 16-bit modes rounds the UN-scaled weight gradient times 2^14 to IEEE half: |dWf| > 4 raises the
  *    same flag, and no loss scale cures that.  Such a fit has diverged; main_train restores the start of the epoch and
  *    continues in a wider precision (bf16 keeps that operand format, fp32 does not have it);
- *  - Adam's step count, in the device schedule and in the checkpoint's optimizer entry, excludes skipped steps. */
+ *  - Adam's step count, in the device schedule and in the checkpoint's optimizer entry, excludes skipped steps;
+ *  - orn_engine_train_steps (pipelined form) advances the schedule every step, like orn_engine_train_step.  The skip decision of a
+ *    step is taken by the Adam launch on the caller's stream, behind every detector that runs there (the loss, the hand-off into
+ *    the fp32 part, the lower blocks' slab reduction and merge-backward pack, the head's dW finish is on the side stream but the dy it
+ *    sums is covered by the lower blocks' detectors: a non-finite dy of the last block reaches them through the dgrad chain), and
+ *    the side stream's Adam launch (last block + head) follows that decision.  Two detectors of the side branch run BEHIND the
+ *    decision: the last block's slab reduction (unreachable alone, by the argument above) and the fp16 copy of its merged-kernel
+ *    gradient (|dWf| > 4).  If one of them fires alone, only the side stream's update of that step is skipped (the parameters stay
+ *    finite; the step is not counted as skipped).  The serial forms skip the whole step in that case. */
 ORN_API int orn_engine_scale_state(orn_engine *e, float *out8);
 /* Overrides the live scale (>= 1) and, if gs_max > 0, its ceiling: tests inject an overflowing step this way. */
 ORN_API int orn_engine_set_grad_scale(orn_engine *e, float gs, float gs_max);
