@@ -332,7 +332,9 @@ def worker(args):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(args.backend, rank=rank, world_size=world)     # "nccl" = RCCL over xGMI
+        # "nccl" = RCCL over xGMI; device_id binds the communicator to this rank's GPU at creation (no reliance on the current device)
+        kw = {'device_id': torch.device('cuda', local)} if (args.backend == 'nccl' and not stub) else {}
+        dist.init_process_group(args.backend, rank=rank, world_size=world, **kw)
     device_sync = (lambda: None) if stub else torch.cuda.synchronize
     cfg = CONFIGS[args.config]
     graph = {'stream': None, 'graph': True, 'eager': False}['eager' if args.no_graph else args.mode]

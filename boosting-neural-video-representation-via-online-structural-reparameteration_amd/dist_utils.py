@@ -37,8 +37,10 @@ def init(backend: str = None, timeout_s: float = None):
     if timeout_s is None:
         timeout_s = float(os.environ.get('ORN_DIST_TIMEOUT_S', DEFAULT_TIMEOUT_S))
     if not dist.is_initialized():
-        dist.init_process_group(backend or ('nccl' if torch.cuda.is_available() else 'gloo'), rank=rank, world_size=world,
-                                timeout=datetime.timedelta(seconds=timeout_s))
+        backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+        # nccl (= RCCL): bind the communicator to this rank's GPU at creation instead of relying on the current device
+        kw = {'device_id': torch.device('cuda', env_world()[1])} if backend == 'nccl' else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s), **kw)
     return dist
 
 
