@@ -13,6 +13,12 @@ carries only the barrier, the max-over-ranks time and the per-rank rates.  Rank 
 The headline `value` is the engine's 16-bit mode (--precision fp16: IEEE-half activations and MFMA operands, fp32
 accumulate, fp32 master weights / merge / loss / Adam, dynamic loss scale).  The reference trains in fp32, so the same
 line carries the fp32 engine's own record under "fp32" (same step, same video, exact-fp32 MFMA), measured in this run.
+
+Launch form (--mode, reported as config.launch_mode): "stream" (default) enqueues the steps through orn_engine_train_steps --
+plain launches; in the 16-bit modes the last block's weight gradient -> slab reduction -> merge backward -> Adam -> next merge
+forward chain of every step runs on a second stream the engine owns, beside the boundary between that step and the next
+ --, "graph" replays the serial step as a hipGraph (rounds 1-3), "eager" calls orn_engine_train_step per step.
+All three compute the same bits.  The per-kernel roofline table is measured on serial eager steps (one kernel at a time).
 """
 import argparse
 import json

@@ -73,12 +73,15 @@ struct orn_engine {
     //   ev_fork   main -> side: dy / x of the last block, the head's partials and the step's copied schedule state are final
     //   ev_adam   main -> side: the step's skip decision has been taken (the side's Adam launch follows it)
     //   ev_wgrad  side -> main: the last block's input buffer may be overwritten (by the forward conv of the block below it)
+    //   ev_below  side -> main: the weight gradient of the block BELOW the last one, which the side stream computes first (beside that
+    //                           block's own dgrad launch on the caller's stream: 230 work-groups on 512 slots at 720p, and a wgrad
+    //                           of 216), is complete: its slabs may be reduced, its input buffer overwritten
     //   ev_join   side -> main: the last block's merged kernel (and the head's parameters) of the next step are ready
     // cur_side / sc_side: this step's schedule entry and loss scale, copied by the loss's finalize stage (the main stream advances
     // to the next step while the side branch still reads them); sc_side->flag also collects what the side branch's own two
     // detectors raise behind the main commit (include/orn.h, the loss-scale comment).
     hipStream_t side;
-    hipEvent_t ev_fork, ev_adam, ev_wgrad, ev_join;
+    hipEvent_t ev_fork, ev_adam, ev_wgrad, ev_join, ev_below;
     OrnStepCur *cur_side;
     OrnScaleState *sc_side;
     size_t side_lo;                  // parameters [side_lo, n_params) belong to the side branch's Adam launch (last block + head)
@@ -93,6 +96,7 @@ struct orn_engine {
 static_assert(ORN_SCALE_SLOTS >= ORN_GRAPH_UNROLL, "one scale-state entry per step of the unrolled graph");
 
 static inline size_t al(size_t floats) { return orn_align(floats * 4) / 4; }
+static bool side_takes_below(const orn_engine *e);
 
 extern "C" size_t orn_conv3x3_ps_silu_bwd_ws_bytes(int B, int C, int O, int H, int W);
 extern "C" size_t orn_erb_merge_bwd_ws_bytes(int C, int O);
@@ -266,7 +270,7 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
     e->graph = nullptr; e->graph_exec = nullptr; e->graph_u = nullptr; e->graph_exec_u = nullptr;
     e->prof = false;
     for (int k = 0; k < 3; ++k) { e->mset[k].n = 0; e->mset[k].mh_host = nullptr; }
-    e->side = nullptr; e->ev_fork = e->ev_adam = e->ev_wgrad = e->ev_join = nullptr;
+    e->side = nullptr; e->ev_fork = e->ev_adam = e->ev_wgrad = e->ev_join = e->ev_below = nullptr;
     e->pipe_ok = false; e->side_busy = false; e->side_lo = 0;
     for (int i = 0; i < 4 * ORN_MAX_LAYERS + 4; ++i) e->prof_ev[i] = nullptr;
     e->ops = (d->precision == 2) ? orn_half_ops_f16() : orn_half_ops_bf16();
@@ -302,9 +306,12 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
             e->side_lo = (size_t)lo;
         }
         if (ok) {
+            // (A high-priority side stream returns ~2 us per step -- the branch's small launches queue less behind the 8-wave forward
+            // launches of the middle blocks -- but while such a queue exists, even idle, every OTHER stream of the process loses: the
+            // fp32 engine's step, run next to an idle fp16 engine, went 6.66 -> 8.25 ms.  Default priority.)
             hipError_t rc = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
-            hipEvent_t *evs[4] = {&e->ev_fork, &e->ev_adam, &e->ev_wgrad, &e->ev_join};
-            for (int k = 0; k < 4 && rc == hipSuccess; ++k) rc = hipEventCreateWithFlags(evs[k], hipEventDisableTiming);
+            hipEvent_t *evs[5] = {&e->ev_fork, &e->ev_adam, &e->ev_wgrad, &e->ev_join, &e->ev_below};
+            for (int k = 0; k < 5 && rc == hipSuccess; ++k) rc = hipEventCreateWithFlags(evs[k], hipEventDisableTiming);
             if (rc != hipSuccess) { orn_set_error("engine_create: side stream: %s", hipGetErrorString(rc)); orn_engine_destroy(e); return (int)rc; }
         }
         e->pipe_ok = ok;
@@ -369,8 +376,8 @@ extern "C" void orn_engine_destroy(orn_engine *e)
     for (int i = 0; i < 4 * ORN_MAX_LAYERS + 4; ++i)
         if (e->prof_ev[i]) (void)hipEventDestroy(e->prof_ev[i]);
     if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
-    hipEvent_t evs[4] = {e->ev_fork, e->ev_adam, e->ev_wgrad, e->ev_join};
-    for (int k = 0; k < 4; ++k) if (evs[k]) (void)hipEventDestroy(evs[k]);
+    hipEvent_t evs[5] = {e->ev_fork, e->ev_adam, e->ev_wgrad, e->ev_join, e->ev_below};
+    for (int k = 0; k < 5; ++k) if (evs[k]) (void)hipEventDestroy(evs[k]);
     for (int k = 0; k < 3; ++k) free(e->mset[k].mh_host);
     delete e;
 }
@@ -570,6 +577,7 @@ static int forward(orn_engine *e, const float *embeds, const int *row_idx, bool 
             const bool last = (i + 1 == nl);
             // pipelined step: the side branch of the previous step still reads the last block's input buffer (its weight gradient)
             // until ev_wgrad, and writes that block's merged kernel (and the head's parameters) until ev_join
+            if (e->side_busy && i + 3 == nl && side_takes_below(e)) ORN_HIP(hipStreamWaitEvent(st, e->ev_below, 0));   // (this conv overwrites the input of the block below the last)
             if (e->side_busy && i + 2 == nl) ORN_HIP(hipStreamWaitEvent(st, e->ev_wgrad, 0));
             if (e->side_busy && last) { ORN_HIP(hipStreamWaitEvent(st, e->ev_join, 0)); e->side_busy = false; }
             if (last) hf = OrnHeadFuse{P + d.head_w, P + d.head_b, e->img, d.sigmoid, 0};
@@ -616,9 +624,10 @@ static OrnMergeMisc merge_misc(const orn_engine *e, int i)
 }
 
 // Split-K slabs of the LAST block's weight gradient on an engine that can run the pipelined step: fewer, longer work-groups (one
-// per CU or less) leave room on every CU for the launches that run beside it.  Measured on the 720p step (tools/probes, round 4):
-// 40 / 24 / 16 slabs = 1.068 / 1.028 / 1.034 ms per pipelined step.  The serial forms of the step use the same count, so that all
-// forms of the step give bit-identical results.
+// per CU, or little more) leave room on every CU for the launches that run beside it.  Measured on the 720p step (tools/probes, round 4):
+// 40 / 32 / 24 slabs = 1.050 / 1.015..1.024 / 1.019..1.023 ms per pipelined step in the final form of the branch (32 and 24
+// are equal within the noise of a box, 24 moves less data).  The serial forms of the step use the same count, so that all forms of
+// the step give bit-identical results.
 static int last_smax(const orn_engine *e)
 {
     static const int smax = orn_probe_env_int("ORN_SIDE_SMAX", 24);
@@ -631,10 +640,22 @@ static int last_smax(const orn_engine *e)
 // 5 (the head) 1.038, 4 1.058, 3 1.024, 2 1.032, 1 1.035, 0 1.067, -1 1.050 ms -- the last block's own dgrad and the launch behind
 // it are full-chip MFMA launches that the side branch's weight gradient only thrashes; behind them the caller's stream runs
 // under-filled launches, and the earlier the branch starts the earlier it is back for the next forward.
+// The side stream also takes the weight gradient of the block below the last one (ahead of the last block's), and then forks one
+// launch earlier, behind the last block's dgrad: that wgrad (216 work-groups at 720p) runs beside the block's own dgrad launch (230
+// work-groups on 512 slots), and the lower blocks' batched wgrad on the caller's stream shrinks to a third (95 -> 40 us at 720p).
+// Same box: 1.037 -> 1.021 ms per step.  ORN_SIDE_BELOW=0: tools/probes A/B.
+static bool side_takes_below(const orn_engine *e)
+{
+    static const bool on = orn_probe_env_int("ORN_SIDE_BELOW", 1) != 0;
+    return on && e->pipe_ok && e->d.n_layers - 2 > e->ff;
+}
+
 static int side_fork_at(const orn_engine *e)
 {
     static const int at = orn_probe_env_int("ORN_SIDE_FORK", -2);
+    if (at == -2 && side_takes_below(e)) return e->d.n_layers - 1;
     if (at == -2) return e->d.n_layers - 2 > e->ff ? e->d.n_layers - 2 : -1;      // default
+    if (side_takes_below(e) && at > e->d.n_layers - 1) return e->d.n_layers - 1;      // (that wgrad needs the last block's dgrad output)
     return at > e->d.n_layers ? e->d.n_layers : at;
 }
 
@@ -650,6 +671,12 @@ static int side_branch_backward(orn_engine *e, hipStream_t st)
     OrnScaleState *sc = e->sc_side;                     // this step's scale, copied by the loss's finalize stage; late detections
     ORN_HIP(hipEventRecord(e->ev_fork, st));
     ORN_HIP(hipStreamWaitEvent(sd, e->ev_fork, 0));
+    if (side_takes_below(e)) {      // (its dy is the output of the dgrad launch this branch forks behind; its slabs are reduced on the caller's stream)
+        const orn_layer_desc &lb = d.layer[nl - 2];
+        const OrnWgradJob wb = {e->L[nl - 2].xpad, e->L[nl - 2].dypad, lb.H, lb.W, lb.C, lb.O, lb.s, e->L[nl - 2].wslab, 0};
+        ORN_TRY(e->ops->wgrad_batch(1, &wb, sd, nullptr, nullptr, 1));
+        ORN_HIP(hipEventRecord(e->ev_below, sd));
+    }
     const OrnWgradJob wj = {e->L[nl - 1].xpad, e->L[nl - 1].dypad, l.H, l.W, l.C, l.O, l.s, e->L[nl - 1].wslab, last_smax(e)};
     const OrnHeadFinish hf = {e->head_ws, e->ops->head_bwd_blocks(e->Hout, e->Wout), e->Cn_last, 1.0f / e->gs, G + d.head_w, G + d.head_b, sc};
     ORN_TRY(e->ops->wgrad_batch(1, &wj, sd, &hf, nullptr, 1));
@@ -781,6 +808,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         int nj = 0;
         const int n_main = pipe ? nl - 1 : nl;      // (pipelined step: the last block's is the side branch's)
         for (int i = n_main - 1; i >= ff; --i) {    // largest first
+            if (pipe && i == nl - 2 && side_takes_below(e)) continue;      // (the side stream's)
             const orn_layer_desc &l = d.layer[i];
             wj[nj++] = OrnWgradJob{e->L[i].xpad, e->L[i].dypad, l.H, l.W, l.C, l.O, l.s, e->L[i].wslab, (i == nl - 1) ? last_smax(e) : 0};
         }
@@ -794,6 +822,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
             wr[i - ff] = OrnWgradReduce{e->L[i].wslab, l.H, l.W, l.C, l.O, l.s, 1.0f / e->gs, G + l.w3x3, G + l.b3x3, sc, (i == nl - 1) ? last_smax(e) : 0};
         }
         if (e->prof) (void)hipEventRecord(e->prof_ev[4 * ORN_MAX_LAYERS + 2], st);
+        if (pipe && side_takes_below(e)) ORN_HIP(hipStreamWaitEvent(st, e->ev_below, 0));
         ORN_TRY(e->ops->wgrad_reduce_all(n_main - ff, wr, st, &w0job));
         if (e->prof) (void)hipEventRecord(e->prof_ev[4 * ORN_MAX_LAYERS + 3], st);
     }

@@ -4,8 +4,9 @@
 PyTorch is the allocator only: the module's parameters are re-homed as views into one flat fp32
 arena (so `state_dict()`, checkpoints and the eager autograd path keep working on the same
 memory), gradients and Adam state get arenas of the same shape, the video is resident in HBM, and
-every step is one hipGraph replay that reads its frame index / LR / step count from a device-side
-schedule.
+every step reads its frame index / LR / step count from a device-side schedule, so whole epochs are
+enqueued without a host sync -- as plain stream launches pipelined over the engine's second stream
+(`run()`'s default, orn_engine_train_steps) or as hipGraph replays of the serial step (`graph=True`).
 """
 import ctypes
 from ctypes import byref, c_int32, c_size_t, c_void_p
