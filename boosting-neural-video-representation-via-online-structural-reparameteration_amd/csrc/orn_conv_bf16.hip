@@ -772,7 +772,7 @@ int orn_wgrad_bf16_split(int H, int W, int O, int smax = 0)
     // layers under 2000 K tiles (720p L3: 900): 24 slabs -- the wgrad launch does not notice (all layers share it), the reduction
     // reads less: 40 / 32 / 24 = 35 / 32 / 30 us
     static const int s_small = orn_probe_env_int("ORN_WGRAD_SMAX_SMALL", 24);   // tools/probes override
-    if (n_ktiles < 2000 && S > s_small) S = s_small;
+    if (n_ktiles < 2000 && S > s_small && smax < 8) S = s_small;     // (a caller's count replaces this rule)
     const int by_work = (n_ktiles / 8) / 8 * 8;
     if (S > by_work) S = by_work;
     if (smax >= 8 && S > smax) S = smax / 8 * 8;   // caller's cap (the engine's side branch runs the last block on fewer, longer work-groups)
@@ -780,7 +780,12 @@ int orn_wgrad_bf16_split(int H, int W, int O, int smax = 0)
     return S;
 }
 
-size_t orn_wgrad_bf16_ws_floats(int H, int W, int O) { return (size_t)orn_wgrad_bf16_split(H, W, O) * (9 * (size_t)O * 96 + O); }
+// (sized for the largest slab count any caller may ask for -- the engine chooses per layer: OrnWgradJob::smax)
+size_t orn_wgrad_bf16_ws_floats(int H, int W, int O)
+{
+    const int S = orn_wgrad_bf16_split(H, W, O), Smax = orn_wgrad_bf16_split(H, W, O, 40);
+    return (size_t)(S > Smax ? S : Smax) * (9 * (size_t)O * 96 + O);
+}
 
 // dwf [O][C][3][3] and dbf [O] (PyTorch channel order), both overwritten.  C <= 96 real channels; xpad always has 96
 // channels per pixel (zeros above C).

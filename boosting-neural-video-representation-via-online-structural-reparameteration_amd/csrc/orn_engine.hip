@@ -650,6 +650,12 @@ static bool side_takes_below(const orn_engine *e)
     return on && e->pipe_ok && e->d.n_layers - 2 > e->ff;
 }
 
+static int below_smax(const orn_engine *e)
+{
+    static const int smax = orn_probe_env_int("ORN_BELOW_SMAX", 0);      // probe: slab cap of the block below the last (0: the default rule)
+    return side_takes_below(e) ? smax : 0;
+}
+
 static int side_fork_at(const orn_engine *e)
 {
     static const int at = orn_probe_env_int("ORN_SIDE_FORK", -2);
@@ -673,7 +679,7 @@ static int side_branch_backward(orn_engine *e, hipStream_t st)
     ORN_HIP(hipStreamWaitEvent(sd, e->ev_fork, 0));
     if (side_takes_below(e)) {      // (its dy is the output of the dgrad launch this branch forks behind; its slabs are reduced on the caller's stream)
         const orn_layer_desc &lb = d.layer[nl - 2];
-        const OrnWgradJob wb = {e->L[nl - 2].xpad, e->L[nl - 2].dypad, lb.H, lb.W, lb.C, lb.O, lb.s, e->L[nl - 2].wslab, 0};
+        const OrnWgradJob wb = {e->L[nl - 2].xpad, e->L[nl - 2].dypad, lb.H, lb.W, lb.C, lb.O, lb.s, e->L[nl - 2].wslab, below_smax(e)};
         ORN_TRY(e->ops->wgrad_batch(1, &wb, sd, nullptr, nullptr, 1));
         ORN_HIP(hipEventRecord(e->ev_below, sd));
     }
@@ -810,7 +816,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         for (int i = n_main - 1; i >= ff; --i) {    // largest first
             if (pipe && i == nl - 2 && side_takes_below(e)) continue;      // (the side stream's)
             const orn_layer_desc &l = d.layer[i];
-            wj[nj++] = OrnWgradJob{e->L[i].xpad, e->L[i].dypad, l.H, l.W, l.C, l.O, l.s, e->L[i].wslab, (i == nl - 1) ? last_smax(e) : 0};
+            wj[nj++] = OrnWgradJob{e->L[i].xpad, e->L[i].dypad, l.H, l.W, l.C, l.O, l.s, e->L[i].wslab, (i == nl - 1) ? last_smax(e) : (i == nl - 2 ? below_smax(e) : 0)};
         }
         const OrnHeadFinish hf = {e->head_ws, e->ops->head_bwd_blocks(e->Hout, e->Wout), e->Cn_last, 1.0f / e->gs, G + d.head_w, G + d.head_b, sc};
         if (e->prof) (void)hipEventRecord(e->prof_ev[4 * ORN_MAX_LAYERS], st);
@@ -819,7 +825,7 @@ static int train_step(orn_engine *e, const float *frames, const float *embeds, c
         OrnWgradReduce wr[ORN_MAX_LAYERS];
         for (int i = ff; i < n_main; ++i) {
             const orn_layer_desc &l = d.layer[i];
-            wr[i - ff] = OrnWgradReduce{e->L[i].wslab, l.H, l.W, l.C, l.O, l.s, 1.0f / e->gs, G + l.w3x3, G + l.b3x3, sc, (i == nl - 1) ? last_smax(e) : 0};
+            wr[i - ff] = OrnWgradReduce{e->L[i].wslab, l.H, l.W, l.C, l.O, l.s, 1.0f / e->gs, G + l.w3x3, G + l.b3x3, sc, (i == nl - 1) ? last_smax(e) : (i == nl - 2 ? below_smax(e) : 0)};
         }
         if (e->prof) (void)hipEventRecord(e->prof_ev[4 * ORN_MAX_LAYERS + 2], st);
         if (pipe && side_takes_below(e)) ORN_HIP(hipStreamWaitEvent(st, e->ev_below, 0));
