@@ -85,6 +85,27 @@ def test_pipelined_steps_equal_eager_steps_at_720p(orn):
         assert torch.equal(a, b), (what, float((a - b).abs().max()))
 
 
+def test_pipelined_epochs_equal_graph_replay_at_720p(orn):
+    """A soak for the hand-offs between the streams (a missed dependency shows as a different bit sooner or later): 3 epochs of the
+    132-frame bench video, shuffled schedule with the reference's LR ramp, as pipelined calls of one epoch each against the hipGraph
+    replay of the serial step -- parameters, both moments and all 396 per-step records bit for bit -- and the pipelined run repeated
+    (run-to-run identical)."""
+    import bench
+    outs = []
+    for mode in (True, None, None):
+        eng = bench.make_engine(seed=11, precision='fp16', cfg=bench.CONFIGS['720p'])
+        eng.set_schedule(bench.schedule(396))
+        for _ in range(3):
+            eng.run(132, graph=mode)
+        torch.cuda.synchronize()
+        outs.append((eng.params.clone(), eng.adam_m.clone(), eng.adam_v.clone(), eng.stats(396).clone()))
+        assert eng.scale_state()['skipped'] == 0
+        del eng
+    for k in (1, 2):
+        for a, b, what in zip(outs[0], outs[k], ('params', 'adam_m', 'adam_v', 'stats')):
+            assert torch.equal(a, b), (k, what, float((a - b).abs().max()))
+
+
 def test_a_skipped_step_is_skipped_on_both_streams(orn):
     """The guard under the pipeline: a step whose gradients overflow (scale forced to 2^40) must leave EVERY parameter and moment
     bit-identical -- the side branch's Adam launch (last block + head) follows the decision the main stream took -- and count once."""
