@@ -70,12 +70,14 @@ def test_pipelined_steps_equal_serial_steps_bit_for_bit(orn, prec, branch, geo):
     assert torch.isfinite(ref[0]).all() and not torch.equal(ref[1], torch.zeros_like(ref[1]))
 
 
-def test_pipelined_steps_equal_eager_steps_at_720p(orn):
-    """BASELINE config 2 at full size: 6 pipelined steps against 6 single-step calls, bit for bit."""
+@pytest.mark.parametrize('cfg', ['720p', '1080p'])
+def test_pipelined_steps_equal_eager_steps_at_720p(orn, cfg):
+    """BASELINE config 2 (720p, 9_16_26) and config 3's geometry (1080p, 9_16_48, a stride-3 block) at full size: 6 pipelined steps
+    against 6 single-step calls, bit for bit."""
     import bench
     outs = []
     for mode in (False, None):
-        eng = bench.make_engine(seed=7, precision='fp16', cfg=bench.CONFIGS['720p'], frames=6)
+        eng = bench.make_engine(seed=7, precision='fp16', cfg=bench.CONFIGS[cfg], frames=6)
         eng.set_schedule([(k % 6, k + 1, 5e-4) for k in range(6)])
         eng.run(6, graph=mode)
         torch.cuda.synchronize()
