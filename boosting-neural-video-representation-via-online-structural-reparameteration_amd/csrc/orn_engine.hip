@@ -311,7 +311,11 @@ extern "C" int orn_engine_create(const orn_engine_desc *d, float *params, float 
             // fp32 engine's step, run next to an idle fp16 engine, went 6.66 -> 8.25 ms.  Default priority.)
             hipError_t rc = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
             hipEvent_t *evs[5] = {&e->ev_fork, &e->ev_adam, &e->ev_wgrad, &e->ev_join, &e->ev_below};
-            for (int k = 0; k < 5 && rc == hipSuccess; ++k) rc = hipEventCreateWithFlags(evs[k], hipEventDisableTiming);
+            // hipEventDisableSystemFence: these events order streams of ONE device; what the flag gives up is visibility to the host and
+            // to other devices at the record (hip_runtime_api.h), which the caller's own synchronisation of its stream provides.  The
+            // record is then a lighter packet: ~4 us per step (3 records / waits on the caller's stream).  ORN_EVENT_FENCE=1: the default events.
+            const unsigned evflags = hipEventDisableTiming | (orn_probe_env("ORN_EVENT_FENCE") ? 0u : (unsigned)hipEventDisableSystemFence);
+            for (int k = 0; k < 5 && rc == hipSuccess; ++k) rc = hipEventCreateWithFlags(evs[k], evflags);
             if (rc != hipSuccess) { orn_set_error("engine_create: side stream: %s", hipGetErrorString(rc)); orn_engine_destroy(e); return (int)rc; }
         }
         e->pipe_ok = ok;
