@@ -52,7 +52,11 @@ int orn_probe_env_int(const char *name, int dflt);
 // Wave priority of the kernels on the caller's stream that run beside the side branch's full-chip weight-gradient launch in the
 // pipelined step (orn_engine.hip): where a SIMD hosts a wave of each, this one issues first -- the caller's stream is the critical
 // path, the side branch has slack (same box, 720p step: 1.045 -> 1.036 ms).  Alone on the chip (serial steps) it changes nothing.
+#ifdef ORN_PRIO_LEVEL      /* tools/probes: tagged builds with another level (0: none) */
+#define ORN_PRIO_HIGH() __builtin_amdgcn_s_setprio(ORN_PRIO_LEVEL)
+#else
 #define ORN_PRIO_HIGH() __builtin_amdgcn_s_setprio(2)
+#endif
 static inline int orn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t orn_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
