@@ -721,9 +721,20 @@ static int side_branch_update(orn_engine *e, bool more)
         int pk_par = 0, pk_t = 0;
         const void *pk = ms.mh_host ? orn_merge_h16_pack(ms.mh_host, &pk_par, &pk_t) : nullptr;
         const OrnLinearJob none = {};
-        ORN_TRY(orn_launch_w2_transpose(ms.n, ms.ml, sd, pk, pk_par));
+        // The pack jobs that ride on these launches in the serial step (half copies for the NEXT merge backward of this block: needed
+        // a whole step later) are launches of their own BEHIND the join event here: the branch's S launch runs while the 8-wave forward
+        // conv of the block below holds all but a few CUs, and 160 rider work-groups in front of its 84 tiles cost it those.
+        static const bool late_packs = orn_probe_env("ORN_SIDE_RIDERS") == nullptr;
+        ORN_TRY(orn_launch_w2_transpose(ms.n, ms.ml, sd, late_packs ? nullptr : pk, late_packs ? 0 : pk_par));
         ORN_TRY(orn_launch_merge_group_linear(ms.tables, 0, ms.tiles[0], none, sd));
-        ORN_TRY(orn_launch_merge_group_linear(ms.tables, 1, ms.tiles[1], none, sd, pk, pk_t));   // the S epilogue writes the 16-bit operand copies
+        ORN_TRY(orn_launch_merge_group_linear(ms.tables, 1, ms.tiles[1], none, sd, late_packs ? nullptr : pk, late_packs ? 0 : pk_t));   // the S epilogue writes the 16-bit operand copies
+        if (late_packs && pk) {
+            ORN_HIP(hipEventRecord(e->ev_join, sd));
+            ORN_TRY(orn_launch_merge_h16_pack_jobs(ms.mh_host, 1, sd));
+            ORN_TRY(orn_launch_merge_h16_pack_jobs(ms.mh_host, 2, sd));
+            e->side_busy = true;
+            return 0;
+        }
     } else {
         const orn_layer_desc &l = d.layer[nl - 1];
         const OrnPrepLayer pl = {e->L[nl - 1].wf, e->L[nl - 1].bf, l.O, l.C, l.s, e->L[nl - 1].wb, e->L[nl - 1].wd, e->L[nl - 1].biasp, ORN_FAST_C};

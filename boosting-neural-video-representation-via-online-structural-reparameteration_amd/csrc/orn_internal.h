@@ -77,6 +77,8 @@ size_t orn_merge_h16_host_bytes();
 int orn_merge_h16_build(void *dev_tables, void *host, int n_layers, const OrnMergeLayer *L, void *const *bufs, OrnScaleState *sc);
 int orn_launch_merge_h16_bwd(const void *dev_tables, const void *host, hipStream_t st, OrnScaleState *sc = nullptr);   // sc: the launching step's scale-state entry
 const void *orn_merge_h16_pack(const void *host, int *par_blocks, int *t_blocks);
+// the parameter-side (which = 1) or T -> Th (which = 2) pack jobs of the set as a launch of their own (instead of riders)
+int orn_launch_merge_h16_pack_jobs(const void *host, int which, hipStream_t st);
 
 // per-layer elementwise tails of the merge, all layers per launch
 struct OrnMergeMisc {

@@ -266,6 +266,16 @@ const void *orn_merge_h16_pack(const void *host, int *par_blocks, int *t_blocks)
     return &H->pack;
 }
 
+int orn_launch_merge_h16_pack_jobs(const void *host, int which, hipStream_t st)
+{
+    const OrnMergeH16 *H = (const OrnMergeH16 *)host;
+    const int blocks = which == MH_TAB_PAR ? H->pack_blocks_par : H->pack_blocks_t;
+    if (blocks <= 0) return 0;
+    hipLaunchKernelGGL(k_merge_pack, dim3(blocks), dim3(256), 0, st, H->pack, which);
+    ORN_LAUNCH_CHECK("merge_pack(jobs)");
+    return 0;
+}
+
 // (parameter-side pack: forward), gradient-side pack, then {dW3, dT}, then {dW2, dW1 partials}; the slices / dW1 sum stay with
 // orn_launch_merge_bwd_tail_all
 int orn_launch_merge_h16_bwd(const void *dev_tables, const void *host, hipStream_t st, OrnScaleState *sc)
