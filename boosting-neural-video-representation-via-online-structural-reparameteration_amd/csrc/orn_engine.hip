@@ -66,8 +66,8 @@ struct orn_engine {
     hipStream_t g_stream;
     // Pipelined form of the step (orn_engine_train_steps; 16-bit engines with >= 2 blocks on the fast path): the LAST block's
     // weight gradient, slab reduction, merge backward, Adam update and next merge forward run on a second stream (`side`),
-    // forked off the caller's stream at the end of the backward and joined in front of the last block's forward conv of the
-    // NEXT step.  That chain -- one full-chip MFMA launch and a tail of small ones -- then runs beside the latency-bound
+    // forked off the caller's stream inside the backward (side_fork_at: behind the last block's dgrad) and joined in front of the
+    // last block's forward conv of the NEXT step.  That chain -- one full-chip MFMA launch and a tail of small ones -- then runs beside the latency-bound
     // launches of the step boundary (merge backward / Adam / merge forward of the lower blocks, stem, first blocks) instead of
     // in front of them.  Same arithmetic as the serial step (bit-identical results); what it needs:
     //   ev_fork   main -> side: dy / x of the last block, the head's partials and the step's copied schedule state are final
@@ -669,8 +669,8 @@ static int side_fork_at(const orn_engine *e)
     return at > e->d.n_layers ? e->d.n_layers : at;
 }
 
-// The side branch of a pipelined step, first half (enqueued where the caller's stream has finished the dgrad chain and the lower
-// blocks' weight gradients): the last block's weight gradient (+ the head's dW / db finish), its slab reduction, its merge backward.
+// The side branch of a pipelined step, first half (enqueued at the fork point, side_fork_at): the weight gradient of the block below the
+// last one (side_takes_below), then the last block's weight gradient (+ the head's dW / db finish), its slab reduction, its merge backward.
 static int side_branch_backward(orn_engine *e, hipStream_t st)
 {
     const orn_engine_desc &d = e->d;
